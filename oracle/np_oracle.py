@@ -1,0 +1,70 @@
+"""oracle/np_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+NumPy term-at-a-time restatement of ``RetrievalService._numpy_bm25_score``
+(/root/reference/rag_system/core/retrieval.py:298-318): for term ids ascending
+(``np.nonzero(query_tf)[0]``, :302) walk the term's column and do, per posting, in fp32
+
+    numerator   = tf * (k1 + 1)                                          (:314)
+    denominator = tf + k1 * (1 - b + b * doc_len / avgdl)                (:315)
+    scores[doc] += idf * (numerator / denominator) * query_weight        (:316)
+
+It is an independent second restatement used to cross-check ``bm25_oracle.c`` (doc-at-a-time) and
+to pin the "precomputed impact" factorisation the HIP index stores.  Slow: small cases only.
+Parity status: PINNED by tests/golden (scores bit-equal to the imported reference).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+
+def impacts_f32(data, row_of_nnz, doc_lengths, k1, b, avgdl) -> np.ndarray:
+    """impact = (tf*(k1+1)) / (tf + k1*(1-b+b*len/avgdl)) in fp32, reference operation order."""
+    f = np.float32
+    tf = np.asarray(data, dtype=f)
+    ln = np.asarray(doc_lengths, dtype=f)[row_of_nnz]
+    norm = f(k1) * (f(1.0 - b) + (f(b) * ln) / f(avgdl))
+    return (tf * f(k1 + 1.0)) / (tf + norm)
+
+
+def bm25_scores_taat(indptr, indices, data, doc_lengths, idf, q_term, q_w, k1=1.2, b=0.75, avgdl=1.0) -> np.ndarray:
+    n = len(indptr) - 1
+    V = len(idf)
+    m = csr_matrix((np.asarray(data, np.float32), np.asarray(indices), np.asarray(indptr)), shape=(n, V)).tocsc()
+    m.sort_indices()
+    scores = np.zeros(n, dtype=np.float32)
+    f = np.float32
+    order = np.argsort(np.asarray(q_term), kind="stable")
+    for i in order:
+        t = int(q_term[i])
+        if t < 0 or t >= V or not (q_w[i] > 0):
+            continue
+        lo, hi = m.indptr[t], m.indptr[t + 1]
+        docs = m.indices[lo:hi]
+        imp = impacts_f32(m.data[lo:hi], docs, doc_lengths, k1, b, avgdl)
+        scores[docs] += (f(idf[t]) * imp) * f(q_w[i])  # docs unique within a term: plain fancy += is exact
+    return scores
+
+
+def tfidf_scores_taat(indptr, indices, data, idf, q_term, q_w) -> np.ndarray:
+    n = len(indptr) - 1
+    V = len(idf)
+    m = csr_matrix((np.asarray(data, np.float32), np.asarray(indices), np.asarray(indptr)), shape=(n, V)).tocsc()
+    m.sort_indices()
+    scores = np.zeros(n, dtype=np.float32)
+    f = np.float32
+    for i in np.argsort(np.asarray(q_term), kind="stable"):
+        t = int(q_term[i])
+        if t < 0 or t >= V or not (q_w[i] > 0):
+            continue
+        lo, hi = m.indptr[t], m.indptr[t + 1]
+        scores[m.indices[lo:hi]] += (m.data[lo:hi] * f(idf[t])) * f(q_w[i])
+    return scores
+
+
+def topk_ranked(scores: np.ndarray, k: int):
+    """(score desc, index asc) top-k by a full lexsort -- the tie contract stated in bm25_oracle.c."""
+    s = np.asarray(scores, dtype=np.float32)
+    order = np.lexsort((np.arange(len(s)), -s.astype(np.float64)))
+    order = order[: min(k, len(s))]
+    return order.astype(np.int64), s[order]

@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference is mounted read-only at /root/reference; it does not
+exist on the GPU box and nothing under tests/ reads it at test time):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/tests/golden/make_golden.py
+
+What is recorded is DATA only -- inputs (texts, CSR arrays, query term lists) and the outputs the
+reference produced for them:
+  text_small.json      corpus + queries + ``RetrievalService.search_bm25`` results (k = 3, 10, 1000)
+  text_small.npz       the index state ``build_bm25_index`` produced (CSR, idf, doc_lengths, avgdl,
+                       vocabulary, doc_ids) + full per-query score vectors from ``_numpy_bm25_score``
+                       and from the plain-Python ``simd_bm25_score``
+  csr_zipf.npz         numeric Zipf CSR pushed through the real ``search_bm25`` (k = 10, 100) and
+                       through ``simd_tfidf_score`` (pipeline twin) with its idf variant
+  registry_small.json  ``OptimizedBM25Retriever`` (registry twin) results on the same text corpus,
+                       bm25 and the registry's tfidf setting (k1=1000, b=0)
+
+numba is not installed here, so the reference runs its own NumPy / plain-Python fallbacks
+(NUMBA_AVAILABLE=False, retrieval.py:22-33).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+import rag_system.core.retrieval as ref_retrieval  # noqa: E402
+from rag_system.core.memory_index import MemoryIndex  # noqa: E402
+
+assert ref_retrieval.NUMBA_AVAILABLE is False
+
+
+def new_service(tmp):
+    p = os.path.join(tmp, "idx.bin")
+    MemoryIndex(p, create=True).close()
+    return ref_retrieval.RetrievalService(p)
+
+
+def zipf_text_corpus(rng, n_docs, vocab_words):
+    """Text in the style of tests/core_test.py:203-252 (Zipf words, gamma lengths)."""
+    V = len(vocab_words)
+    p = 1.0 / np.arange(1, V + 1)
+    p /= p.sum()
+    corpus = {}
+    for i in range(n_docs):
+        ln = int(np.clip(rng.gamma(2.0, 12.0), 3, 80))
+        words = rng.choice(V, size=ln, p=p)
+        corpus[f"doc{i}"] = {"text": " ".join(vocab_words[w] for w in words), "title": f"Title {i}"}
+    return corpus
+
+
+def make_text_fixture(tmp):
+    rng = np.random.default_rng(20250)
+    vocab_words = [f"w{i}" for i in range(400)] + ["café", "naïve", "straße", "東京", "данные", "x_1", "e2e"]
+    corpus = zipf_text_corpus(rng, 300, vocab_words)
+    # edge-case documents (retrieval.py:145: text -> content -> body fallback; title never indexed)
+    corpus["edge_content"] = {"content": "Don't panic: the U.S.A. costs 3.14 dollars; CAFÉ café Café!"}
+    corpus["edge_body"] = {"body": "İstanbul straße 東京 東京 данные x_1 e2e w1 w1 w1 w2"}
+    corpus["edge_empty"] = {"text": ""}
+    corpus["edge_title_only"] = {"title": "w1 w2 w3 only a title"}
+    corpus["edge_punct"] = {"text": "... !!! ???"}
+    corpus["edge_dup_a"] = {"text": "w7 w8 w9 w7"}
+    corpus["edge_dup_b"] = {"text": "w7 w8 w9 w7"}  # exact score tie with edge_dup_a
+    corpus["edge_long"] = {"text": " ".join(["w3 w4 w5"] * 60)}
+    svc = new_service(tmp)
+    svc.build_bm25_index(corpus)
+
+    queries = {}
+    for i in range(30):
+        ln = int(np.clip(rng.gamma(1.5, 2.5), 1, 10))
+        words = rng.choice(120, size=ln)  # from the frequent part of the vocabulary
+        queries[f"q{i}"] = " ".join(vocab_words[w] for w in words)
+    queries.update({
+        "q_blank": "   ",
+        "q_empty": "",
+        "q_oov": "zzzunknown qqqmissing",
+        "q_punct": "?!",
+        "q_negidf": "w0",                  # df > N/2 -> negative idf -> no positive score
+        "q_negidf_mix": "w0 w0 w250 w399",
+        "q_repeat": "w7 w7 w7 w8",
+        "q_tie": "w9 w8 w7",
+        "q_unicode": "CAFÉ 東京 Данные straße",
+        "q_apostrophe": "don't u.s.a. 3.14",
+        "q_mixed_oov": "w5 notaword w6",
+        "q_long": " ".join(f"w{i}" for i in range(0, 140, 2)),  # 70 distinct terms
+    })
+    results = {}
+    for k in (3, 10, 1000):
+        svc.clear_cache()
+        results[str(k)] = svc.search_bm25(queries, top_k=k)
+    # cache-hit path (retrieval.py:216-225) must give the same dict
+    again = svc.search_bm25(queries, top_k=1000)
+    assert again == results["1000"]
+
+    # full score vectors
+    score_q = [q for q in queries if q.startswith("q") and queries[q].strip()]
+    full_numpy, full_simd, qterms, qweights, qnames = [], [], [], [], []
+    import re
+    from collections import Counter
+    for qid in score_q:
+        toks = re.findall(r"\b\w+\b", queries[qid].lower())
+        cnt = Counter(toks)
+        qtf = np.zeros(len(svc.vocabulary), dtype=np.float32)
+        for t, c in cnt.items():
+            if t in svc.vocabulary:
+                qtf[svc.vocabulary[t]] = float(c)
+        if not qtf.any():
+            continue
+        s_np = svc._numpy_bm25_score(qtf)
+        s_simd = ref_retrieval.simd_bm25_score(qtf, svc.corpus_tf.data, svc.corpus_tf.indices, svc.corpus_tf.indptr,
+                                               svc.doc_lengths, svc.idf_weights, svc.k1, svc.b, svc.avgdl)
+        assert np.array_equal(s_np, s_simd), qid
+        nz = np.nonzero(qtf)[0]
+        qnames.append(qid)
+        qterms.append(nz.astype(np.int32))
+        qweights.append(qtf[nz])
+        full_numpy.append(s_np.astype(np.float32))
+    q_ptr = np.zeros(len(qterms) + 1, dtype=np.int32)
+    q_ptr[1:] = np.cumsum([len(t) for t in qterms])
+    vocab_sorted = sorted(svc.vocabulary, key=svc.vocabulary.get)
+    np.savez_compressed(
+        os.path.join(OUT, "text_small.npz"),
+        tf_data=svc.corpus_tf.data, tf_indices=svc.corpus_tf.indices, tf_indptr=svc.corpus_tf.indptr,
+        tf_shape=np.array(svc.corpus_tf.shape, dtype=np.int64), doc_lengths=svc.doc_lengths, idf=svc.idf_weights,
+        avgdl=np.float64(svc.avgdl), k1=np.float64(svc.k1), b=np.float64(svc.b),
+        vocabulary=np.array(vocab_sorted), doc_ids=np.array(svc.doc_ids),
+        score_qids=np.array(qnames), score_q_ptr=q_ptr, score_q_term=np.concatenate(qterms),
+        score_q_weight=np.concatenate(qweights), full_scores=np.stack(full_numpy),
+    )
+    with open(os.path.join(OUT, "text_small.json"), "w", encoding="utf-8") as f:
+        json.dump({"corpus": corpus, "queries": queries, "results": results,
+                   "stats": {k: v for k, v in svc.get_stats().items()}}, f, ensure_ascii=False, indent=0)
+    svc.close()
+    return corpus, queries
+
+
+def make_csr_fixture(tmp):
+    """Numeric CSR (no text): Zipf term ids, pushed through the REAL search_bm25 by giving the service
+    a vocabulary of synthetic tokens t<id> (zero-padded so that sorted order == id order)."""
+    rng = np.random.default_rng(20251)
+    n_docs, V = 3000, 600
+    p = 1.0 / np.arange(1, V + 1) ** 1.0
+    p /= p.sum()
+    rows, cols, vals = [], [], []
+    doc_len = np.zeros(n_docs, dtype=np.float32)
+    for d in range(n_docs):
+        ln = int(np.clip(rng.gamma(2.0, 15.0), 2, 120))
+        terms, counts = np.unique(rng.choice(V, size=ln, p=p), return_counts=True)
+        rows += [d] * len(terms)
+        cols += terms.tolist()
+        vals += counts.astype(np.float32).tolist()
+        doc_len[d] = ln
+    from scipy.sparse import csr_matrix
+    m = csr_matrix((np.array(vals, np.float32), (rows, cols)), shape=(n_docs, V), dtype=np.float32)
+    m.sort_indices()
+    svc = new_service(tmp)
+    svc.corpus_tf = m
+    svc.vocabulary = {f"t{i:04d}": i for i in range(V)}
+    svc.doc_ids = [str(i) for i in range(n_docs)]
+    svc.doc_lengths = doc_len
+    df = np.bincount(m.indices, minlength=V)
+    svc.idf_weights = np.log((n_docs - df + 0.5) / (df + 0.5)).astype(np.float32)  # retrieval.py:189
+    svc.avgdl = float(np.mean(doc_len))                                              # retrieval.py:190
+    nq = 48
+    qterms, qweights, texts = [], [], {}
+    for q in range(nq):
+        nt = int(rng.integers(1, 12))
+        ts = rng.choice(V, size=nt, p=p)
+        terms, counts = np.unique(ts, return_counts=True)
+        qterms.append(terms.astype(np.int32))
+        qweights.append(counts.astype(np.float32))
+        texts[f"{q}"] = " ".join(f"t{t:04d}" for t in ts)
+    res = {}
+    for k in (10, 100):
+        svc.clear_cache()
+        out = svc.search_bm25(texts, top_k=k)
+        docs = np.full((nq, k), -1, dtype=np.int32)
+        scs = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        for q in range(nq):
+            items = list(out[f"{q}"].items())
+            cnt[q] = len(items)
+            for j, (d, s) in enumerate(items):
+                docs[q, j] = int(d)
+                scs[q, j] = np.float32(s)
+        res[k] = (docs, scs, cnt)
+    # tf-idf twin (pipeline copy): simd_tfidf_score + idf = log(N/(df+1)) (evaluate_rag_pipeline.py:95-121, 273-278)
+    cwd = os.getcwd()
+    os.chdir(tmp)  # the pipeline module writes .rag_cache/ into the CWD
+    with contextlib.redirect_stdout(io.StringIO()):
+        import rag_system.pipeline.evaluate_rag_pipeline as ref_pipe
+    os.chdir(cwd)
+    idf_tfidf = np.log(n_docs / (df + 1)).astype(np.float32)
+    tfidf_full = []
+    for q in range(16):
+        qtf = np.zeros(V, dtype=np.float32)
+        qtf[qterms[q]] = qweights[q]
+        tfidf_full.append(np.asarray(ref_pipe.simd_tfidf_score(qtf, m.data, m.indices, m.indptr, idf_tfidf),
+                                     dtype=np.float32))
+    bm25_full = []
+    for q in range(16):
+        qtf = np.zeros(V, dtype=np.float32)
+        qtf[qterms[q]] = qweights[q]
+        bm25_full.append(svc._numpy_bm25_score(qtf))
+    q_ptr = np.zeros(nq + 1, dtype=np.int32)
+    q_ptr[1:] = np.cumsum([len(t) for t in qterms])
+    np.savez_compressed(
+        os.path.join(OUT, "csr_zipf.npz"),
+        tf_data=m.data, tf_indices=m.indices, tf_indptr=m.indptr, tf_shape=np.array(m.shape, dtype=np.int64),
+        doc_lengths=doc_len, idf=svc.idf_weights, idf_tfidf=idf_tfidf, avgdl=np.float64(svc.avgdl),
+        k1=np.float64(svc.k1), b=np.float64(svc.b),
+        q_ptr=q_ptr, q_term=np.concatenate(qterms), q_weight=np.concatenate(qweights),
+        top10_doc=res[10][0], top10_score=res[10][1], top10_count=res[10][2],
+        top100_doc=res[100][0], top100_score=res[100][1], top100_count=res[100][2],
+        bm25_full=np.stack(bm25_full), tfidf_full=np.stack(tfidf_full),
+    )
+    svc.close()
+
+
+def make_registry_fixture(tmp, corpus, queries):
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import rag_system.core.retriever_registry as ref_reg
+        out = {}
+        for name, cfg in (("bm25", {"type": "bm25", "params": {"k1": 1.2, "b": 0.75}}),
+                          ("bm25_msmarco", {"type": "bm25_custom", "params": {"k1": 1.6, "b": 0.8}}),
+                          ("tfidf", {"type": "tfidf"})):
+            r = ref_reg.RetrieverRegistry.create(cfg)
+            r.build_index_from_corpus(corpus)
+            out[name] = {"k1": r.k1, "b": r.b, "results": {str(k): r.search(queries, top_k=k) for k in (5, 50)}}
+    os.chdir(cwd)
+    with open(os.path.join(OUT, "registry_small.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=0)
+
+
+if __name__ == "__main__":
+    with tempfile.TemporaryDirectory() as tmp:
+        corpus, queries = make_text_fixture(tmp)
+        make_csr_fixture(tmp)
+        make_registry_fixture(tmp, corpus, queries)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
