@@ -1,0 +1,154 @@
+/*
+ * sparse_rx.h -- C ABI of libsparse_rx.so, the MI355X (gfx950) scoring + top-k engine.
+ *
+ * The reference (100 % Python) has no FFI; its hot path is two Numba kernels called from
+ * RetrievalService._score_bm25_query.  This header is the boundary a maintainer binds with ctypes
+ *  to replace exactly those call sites.  Paths are relative to /root/reference:
+ *
+ *   srx_search            replaces  simd_bm25_score(...)        rag_system/core/retrieval.py:256-266
+ *                                   + fast_topk_selection(...)  rag_system/core/retrieval.py:273 (NumPy twin 276-284)
+ *                                   + the score>0 filter        rag_system/core/retrieval.py:292-296
+ *                         (twins: rag_system/core/retriever_registry.py:287-297,304;
+ *                                 rag_system/pipeline/evaluate_rag_pipeline.py:380-399,406 incl. simd_tfidf_score)
+ *   srx_build_impacts     evaluates the per-posting BM25 term  retrieval.py:58,70-71  once at index build
+ *   srx_build_tile_skip   device index construction (no reference counterpart: the reference scans the
+ *                         whole doc-major CSR per query, retrieval.py:55-72)
+ *   srx_merge_topk        the (score desc, doc asc) merge of per-shard / per-split top-k lists
+ *                         (multi-GPU: after the RCCL all-gather; no reference counterpart)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.  Every array pointer is a DEVICE
+ *     pointer (e.g. torch.Tensor.data_ptr()) unless the parameter name starts with h_.
+ *   - The caller owns every buffer (index arrays, queries, outputs, workspace).  The library owns only
+ *     the small srx_index handle.  srx_search allocates nothing and is asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).
+ *   - Return value 0 = OK, negative = error (srx_status); srx_last_error() returns a thread-local
+ *     message.  The Python shim maps them to ValueError / RuntimeError.
+ *   - Not thread-safe per handle; re-entrant across handles / streams.
+ */
+#ifndef SPARSE_RX_H
+#define SPARSE_RX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRX_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    SRX_OK = 0,
+    SRX_ERR_INVALID = -1, /* bad argument */
+    SRX_ERR_HIP = -2,     /* HIP runtime error */
+    SRX_ERR_NOMEM = -3,   /* workspace too small */
+    SRX_ERR_NODEVICE = -4 /* no usable GPU */
+} srx_status;
+
+typedef enum {
+    SRX_VAL_F32 = 0, /* post_val is float32 (BM25 impacts, or raw weights in dot mode) */
+    SRX_VAL_F16 = 1  /* post_val is IEEE half (learned-sparse "dot" mode, SPLADE-style) */
+} srx_val_type;
+
+/* Limits of this build (srx_limits() returns them at run time). */
+#define SRX_MAX_K 1024         /* largest top-k */
+#define SRX_MAX_TILE_LOG2 14   /* skip-table granularity G = 2^tile_log2 docs, G <= 16384 */
+
+/*
+ * Device-resident inverted index of one doc-range shard (term-major CSC + tile skip table).
+ *   term_ptr[t] .. term_ptr[t+1]   postings of term t, ascending shard-local doc id
+ *   post_doc[p]                    shard-local doc row of posting p
+ *   post_val[p]                    BM25: impact = (tf*(k1+1)) / (tf + k1*(1-b+b*len/avgdl)) precomputed in fp32
+ *                                  (retrieval.py:58,70-71); dot mode: the stored weight (tf)
+ *   tile_skip[t*(n_tiles+1) + j]   number of postings of term t with doc < j*G  (so the run of term t
+ *                                  inside docs [a*G, b*G) is [term_ptr[t]+skip[a], term_ptr[t]+skip[b]) )
+ *   idf[t]                         per-term weight (retrieval.py:189; evaluate_rag_pipeline.py:273-278)
+ * Per-posting contribution at query time: (post_val * idf[t]) * q_weight, fp32, summed per doc in
+ * ascending term id -- bit-identical to retrieval.py:72 / evaluate_rag_pipeline.py:117.
+ */
+typedef struct {
+    int32_t device;    /* HIP device ordinal the pointers live on */
+    int32_t val_type;  /* srx_val_type */
+    int64_t n_docs;    /* shard-local rows */
+    int64_t vocab;
+    int64_t nnz;
+    int64_t doc_base;  /* global row id of local row 0 (added to the ids srx_search returns) */
+    int32_t tile_log2; /* G = 1 << tile_log2, <= SRX_MAX_TILE_LOG2 */
+    int32_t n_tiles;   /* ceil(n_docs / G) */
+    const int64_t *term_ptr;  /* [vocab+1] */
+    const int32_t *post_doc;  /* [nnz] */
+    const void *post_val;     /* [nnz] f32 or f16 */
+    const int32_t *tile_skip; /* [vocab*(n_tiles+1)] */
+    const float *idf;         /* [vocab] */
+} srx_index_desc;
+
+typedef struct srx_index srx_index;
+
+/* Search-time tuning knobs; zero-initialise for defaults. */
+typedef struct {
+    int32_t supertile_log2; /* docs per hash-accumulated unit = 2^supertile_log2 (>= tile_log2); 0 = auto */
+    int32_t target_blocks;  /* workgroups to aim for when splitting a query's doc range; 0 = auto (2048) */
+    int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
+    int32_t reserved;
+} srx_search_opts;
+
+int srx_version(void);
+const char *srx_last_error(void);
+/* out[0]=max k, out[1]=max tile_log2, out[2]=hash capacity (postings per unit), out[3]=threads per workgroup */
+int srx_limits(int32_t *h_out4);
+/* Number of visible HIP devices, or a negative srx_status. */
+int srx_device_count(void);
+
+int srx_index_create(const srx_index_desc *h_desc, srx_index **h_out);
+void srx_index_destroy(srx_index *ix);
+int srx_index_set_opts(srx_index *ix, const srx_search_opts *h_opts);
+
+/* Bytes of device workspace srx_search needs for a batch of nq queries at top-k k. */
+int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int32_t k);
+
+/*
+ * Batched scoring + top-k.  Queries are a CSR batch: query q has terms q_term[q_ptr[q] .. q_ptr[q+1])
+ * (ascending, unique, in-vocabulary -- OOV terms dropped on the host as retrieval.py:245-249 does) with
+ * weights q_weight (> 0; the term count as float, retrieval.py:248).
+ * Outputs, row q: out_doc[q*k + r] = doc_base + local row of rank r, out_score[q*k + r] its fp32 score,
+ * r < out_count[q]; rank order = (score descending, doc ascending); only score > 0 (retrieval.py:295);
+ * the rest of the row is padded with doc -1 / score 0.
+ */
+int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+               int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+               int64_t workspace_bytes, void *stream);
+
+/*
+ * Merge n_lists candidate lists per query into one ranked top-k list (same order and padding as
+ * srx_search).  gathered == 0: in_doc/in_score are [nq][n_lists][k], in_count [nq][n_lists];
+ * gathered == 1: [n_lists][nq][k] and [n_lists][nq] -- the layout an all-gather of per-rank srx_search
+ * outputs produces.  Doc ids are taken as they are (global).  workspace may be NULL when
+ * n_lists*k <= 4096, otherwise srx_merge_workspace_bytes() bytes.
+ */
+int64_t srx_merge_workspace_bytes(int32_t nq, int32_t n_lists, int32_t k);
+int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count,
+                   int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
+                   int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- device-side index construction helpers ------------------------------------------------------ */
+
+/* impact[p] = (tf[p]*(k1+1)) / (tf[p] + k1*(1-b + b*doc_len[post_doc[p]]/avgdl)), fp32, the reference's
+ * operation order (retrieval.py:58,70-71): f32(k1)*(f32(1-b) + (f32(b)*len)/f32(avgdl)). */
+int srx_build_impacts(int32_t device, const float *tf, const int32_t *post_doc, const float *doc_len, int64_t nnz,
+                      double k1, double b, double avgdl, float *out_impact, void *stream);
+
+/* tile_skip[t*(n_tiles+1)+j] = #postings of term t with doc < j<<tile_log2  (lower_bound per (t, j)). */
+int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *post_doc, int64_t vocab,
+                        int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
+
+/* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
+/* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = score
+ * kernel, h_ms[1] = merge kernel, h_ms[2] = whole call (milliseconds, hipEventElapsedTime between events
+ * recorded on the search stream around each kernel).  Synchronises the events, resets the window and returns
+ * the number of calls averaged (or a negative srx_status). */
+int srx_profile_read(srx_index *ix, float *h_ms3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSE_RX_H */

@@ -1,0 +1,9 @@
+"""sparse-rx: MI355X-native batched BM25 / learned-sparse scoring + top-k behind the reference's
+``RetrievalService.build_bm25_index()`` / ``search_bm25()`` API.  Import as ``sparse_rx``."""
+from . import _capi
+from ._capi import SparseRxError, SparseRxUnavailable, build_library
+from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, merge_topk_device, tokenize
+from .service import RetrievalService
+
+__all__ = ["RetrievalService", "DeviceIndex", "HostIndex", "build_host_index", "encode_queries", "merge_topk_device",
+           "tokenize", "build_library", "SparseRxError", "SparseRxUnavailable", "_capi"]

@@ -1,0 +1,121 @@
+"""ctypes binding of libsparse_rx.so (C ABI declared in include/sparse_rx.h).
+
+The library is the product: there is no CPU fallback.  If it is missing or cannot be loaded every entry point
+raises ``SparseRxUnavailable`` -- loudly, never a silent eager path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "libsparse_rx.so")
+SRC_PATH = os.path.join(_PKG_DIR, "csrc", "sparse_rx.hip")
+INCLUDE_DIR = os.path.join(_ROOT, "include")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
+               "-std=c++17"]
+
+SRX_VAL_F32, SRX_VAL_F16 = 0, 1
+
+
+class SparseRxUnavailable(RuntimeError):
+    """libsparse_rx.so is not built / not loadable (the HIP engine is mandatory)."""
+
+
+class SparseRxError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class IndexDesc(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("val_type", ctypes.c_int32), ("n_docs", ctypes.c_int64),
+                ("vocab", ctypes.c_int64), ("nnz", ctypes.c_int64), ("doc_base", ctypes.c_int64),
+                ("tile_log2", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("term_ptr", ctypes.c_void_p),
+                ("post_doc", ctypes.c_void_p), ("post_val", ctypes.c_void_p), ("tile_skip", ctypes.c_void_p),
+                ("idf", ctypes.c_void_p)]
+
+
+class SearchOpts(ctypes.Structure):
+    _fields_ = [("supertile_log2", ctypes.c_int32), ("target_blocks", ctypes.c_int32), ("profile", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+# every symbol include/sparse_rx.h declares: name -> (restype, argtypes)
+_VP, _I32, _I64, _DBL = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+SYMBOLS = {
+    "srx_version": (ctypes.c_int, []),
+    "srx_last_error": (ctypes.c_char_p, []),
+    "srx_limits": (ctypes.c_int, [ctypes.POINTER(_I32)]),
+    "srx_device_count": (ctypes.c_int, []),
+    "srx_index_create": (ctypes.c_int, [ctypes.POINTER(IndexDesc), ctypes.POINTER(_VP)]),
+    "srx_index_destroy": (None, [_VP]),
+    "srx_index_set_opts": (ctypes.c_int, [_VP, ctypes.POINTER(SearchOpts)]),
+    "srx_search_workspace_bytes": (_I64, [_VP, _I32, _I32]),
+    "srx_search": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_merge_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "srx_merge_topk": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
+    "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/sparse_rx.hip for gfx950 with hipcc into <package>/libsparse_rx.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "sparse_rx.h"))):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise SparseRxUnavailable("hipcc not found: cannot build libsparse_rx.so")
+    cmd = [hipcc, *HIPCC_FLAGS, f"-I{INCLUDE_DIR}", "-o", LIB_PATH, SRC_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library (symbols typed).  Raises SparseRxUnavailable if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SparseRxUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SparseRxUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            f = getattr(L, name)
+        except AttributeError as e:
+            raise SparseRxUnavailable(f"{LIB_PATH} does not export {name}") from e
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = lib().srx_last_error()
+        text = msg.decode("utf-8", "replace") if msg else ""
+        if rc == -1:
+            raise ValueError(f"{what}: {text}")
+        raise SparseRxError(f"{what} failed ({rc}): {text}")
+    return rc
+
+
+def limits():
+    out = (ctypes.c_int32 * 4)()
+    check(lib().srx_limits(out), "srx_limits")
+    return {"max_k": out[0], "max_tile_log2": out[1], "hash_cap": out[2], "threads": out[3]}

@@ -1,0 +1,1064 @@
+// sparse_rx.hip -- hand-written CDNA4 (gfx950) kernels + the C ABI of libsparse_rx.so.
+//
+// Hot path replaced (paths relative to /root/reference):
+//   simd_bm25_score      rag_system/core/retrieval.py:41-76      (doc-major full CSR scan per query)
+//   simd_tfidf_score     rag_system/pipeline/evaluate_rag_pipeline.py:95-121
+//   fast_topk_selection  rag_system/core/retrieval.py:79-92      (+ score>0 filter :292-296)
+//
+// Design: the index is term-major (CSC) with a tile skip table.  One 256-thread
+// workgroup walks one (query, doc-range split); the split is cut into *units* of docs.  A unit's
+// postings are streamed from HBM with coalesced loads (terms ascending) and accumulated per doc in LDS:
+//   sparse unit  (<= HASH_CAP postings)  -> open-addressing hash table in LDS  (doc -> fp32 sum)
+//   dense tile   (more than that in G docs) -> dense fp32 accumulators acc[G] in LDS
+// Contributions of one doc are added in ascending term id (barrier between terms), so sums are
+// bit-identical to the reference's CSR row order.  After each unit an exact radix select keeps the
+// running top-k (score desc, doc asc) in LDS.  A second kernel merges the per-split lists and sorts.
+// No MFMA (sparse gather/reduce, HBM-bound), no global float atomics (order must be deterministic).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no fused multiply-add: the reference's
+// arithmetic is separate fp32 multiply / add / IEEE divide).
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "sparse_rx.h"
+
+#define SRX_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+constexpr int TBL_WORDS = 16384;            // 64 KiB LDS: hash table (keys+vals) or dense accumulators
+constexpr int SLOTS = TBL_WORDS / 2;        // 8192 hash slots
+constexpr int HASH_CAP = 4096;              // max postings accumulated by one hash unit (load <= 0.5)
+constexpr int NPT_HASH = SLOTS / THREADS;   // 32 table slots per thread
+constexpr int MAX_G = TBL_WORDS;            // dense tile <= 16384 docs
+constexpr int NPT_DENSE = MAX_G / THREADS;  // 64
+constexpr int KMAX = SRX_MAX_K;             // 1024
+constexpr int KPT = KMAX / THREADS;         // 4 running-list entries per thread
+constexpr int MAXT = 256;                   // query terms handled per pass (one per thread)
+constexpr int MAX_STEPS = MAXT + HASH_CAP / THREADS + 16;  // step table entries of a hash unit
+constexpr int PREFETCH = 8;                 // posting loads in flight per thread
+constexpr int RADIX_BITS = 11;
+constexpr int RADIX_BINS = 1 << RADIX_BITS;  // 2048-bin histogram (aliases the table region)
+constexpr int MAX_TPS = 64;                 // tiles per supertile handled by the overflow packer
+constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thread (4096 per workgroup)
+constexpr int EMPTY_KEY = -1;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) return fail(SRX_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+struct IndexView {
+    const int64_t *term_ptr;
+    const int32_t *post_doc;
+    const void *post_val;
+    const int32_t *tile_skip;
+    const float *idf;
+    int64_t n_docs;
+    int64_t vocab;
+    int32_t tile_log2;
+    int32_t n_tiles;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave / block primitives (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// All three return the block-wide value to every thread.  `red` = 3*WAVES words of LDS.  Ends with a
+// barrier, so `red` may be reused immediately.
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+struct SumMaxMin {
+    unsigned sum, mx, mn;
+};
+__device__ __forceinline__ SumMaxMin block_sum_max_min(unsigned s, unsigned mx, unsigned mn, unsigned *red) {
+    s = wave_sum(s);
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s;
+        red[WAVES + (threadIdx.x >> 6)] = mx;
+        red[2 * WAVES + (threadIdx.x >> 6)] = mn;
+    }
+    __syncthreads();
+    SumMaxMin r;
+    r.sum = red[0] + red[1] + red[2] + red[3];
+    r.mx = max(max(red[WAVES + 0], red[WAVES + 1]), max(red[WAVES + 2], red[WAVES + 3]));
+    r.mn = min(min(red[2 * WAVES + 0], red[2 * WAVES + 1]), min(red[2 * WAVES + 2], red[2 * WAVES + 3]));
+    __syncthreads();
+    return r;
+}
+
+// Exclusive prefix sum over the block (thread order); total returned through *total.
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *red, unsigned *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned w = __shfl_up(inc, o);
+        if (lane >= o) inc += w;
+    }
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        unsigned x = red[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact k-th largest of the block's keys (radix select, MSD, 11-bit digits, LDS histogram).
+// key == 0 means "not a candidate"; all candidate keys are in [1, 2^31).  Requires
+// 1 <= k <= #candidates.  mx / mn = max / min over candidate keys.  Returns T = the k-th largest
+// key; n_gt = #keys > T (< k), n_eq = #keys == T (>= k - n_gt).
+// hist: RADIX_BINS words, red: >= 16 words of LDS.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ unsigned radix_kth(const unsigned (&key)[N], unsigned k, unsigned mx, unsigned mn, unsigned n_cand,
+                              unsigned *hist, unsigned *red, unsigned *n_gt, unsigned *n_eq) {
+    if (mx == mn) {
+        *n_gt = 0;
+        *n_eq = n_cand;
+        return mx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = 31 - __clz(mx ^ mn);  // highest bit in which candidates differ (<= 30)
+    unsigned prefix = mx & ~((2u << hb) - 1u);
+    int shift = hb + 1;
+    unsigned krem = k, gt = 0, eq = 0;
+    while (shift > 0) {
+        const int w = shift < RADIX_BITS ? shift : RADIX_BITS;
+        shift -= w;
+        const int hi_shift = shift + w;  // <= 31
+        for (int i = tid; i < RADIX_BINS; i += THREADS) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const unsigned x = key[n];
+            if (x != 0 && ((x ^ prefix) >> hi_shift) == 0) atomicAdd(&hist[(x >> shift) & ((1u << w) - 1u)], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins [8t, 8t+8); find the bin holding the krem-th largest
+        const uint4 a = reinterpret_cast<const uint4 *>(hist)[2 * tid];
+        const uint4 b = reinterpret_cast<const uint4 *>(hist)[2 * tid + 1];
+        const unsigned h[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const unsigned s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+        unsigned suf = s;  // inclusive suffix sum over threads >= tid
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned v = __shfl_down(suf, o);
+            if (lane + o < 64) suf += v;
+        }
+        if (lane == 0) red[wave] = suf;
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww)
+            if (ww > wave) suf += red[ww];
+        const unsigned above = suf - s;
+        if (above < krem && krem <= suf) {
+            unsigned run = above;
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                if (run + h[i] >= krem) {
+                    red[8] = (unsigned)(8 * tid + i);
+                    red[9] = run;
+                    red[10] = h[i];
+                    break;
+                }
+                run += h[i];
+            }
+        }
+        __syncthreads();
+        const unsigned d = red[8], ab = red[9];
+        eq = red[10];
+        krem -= ab;
+        gt += ab;
+        prefix |= d << shift;
+        __syncthreads();
+    }
+    *n_gt = gt;
+    *n_eq = eq;
+    return prefix;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Running top-k list of a workgroup, kept in LDS (unordered).  `tau` = key of the k-th best once a
+// selection has run (0 before): a later candidate with key < tau cannot enter.
+// Total order: larger score first, then smaller doc ("key2" = 0x7FFFFFFF - doc, larger first).
+// ------------------------------------------------------------------------------------------------
+struct TopkShared {
+    unsigned bits[KMAX];
+    int doc[KMAX];
+    unsigned count;
+    unsigned tau;
+    unsigned red[16];
+};
+
+// Fold the candidates of one unit (register arrays ubits/udoc, ubits == 0 -> none) into the list.
+// Candidates must already satisfy ubits >= tau.  hist = RADIX_BINS words of free LDS.
+template <int N>
+__device__ void topk_fold(unsigned (&ubits)[N], const int (&udoc)[N], int k, TopkShared &tk, unsigned *hist) {
+    const int tid = threadIdx.x;
+    const unsigned n_old = tk.count;  // read BEFORE the barriers below: later appends must not be seen by slow threads
+    unsigned mine = 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) mine += (ubits[n] != 0);
+    const unsigned n_new = block_sum(mine, tk.red);
+    if (n_new == 0) return;
+    if (n_old + n_new <= (unsigned)k) {
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+            if (ubits[n] != 0) {
+                const unsigned p = atomicAdd(&tk.count, 1u);
+                tk.bits[p] = ubits[n];
+                tk.doc[p] = udoc[n];
+            }
+        __syncthreads();
+        return;
+    }
+    // selection over (list U candidates)
+    unsigned key[N + KPT];
+    int doc[N + KPT];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        key[n] = ubits[n];
+        doc[n] = udoc[n];
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const unsigned i = tid + j * THREADS;
+        const bool ok = i < n_old;
+        key[N + j] = ok ? tk.bits[i] : 0u;
+        doc[N + j] = ok ? tk.doc[i] : 0;
+    }
+    unsigned lmx = 0, lmn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int n = 0; n < N + KPT; ++n)
+        if (key[n] != 0) {
+            lmx = max(lmx, key[n]);
+            lmn = min(lmn, key[n]);
+        }
+    const SumMaxMin r = block_sum_max_min(0u, lmx, lmn, tk.red);  // also orders the list reads above
+    unsigned n_gt, n_eq;
+    const unsigned T = radix_kth<N + KPT>(key, (unsigned)k, r.mx, r.mn, n_old + n_new, hist, tk.red, &n_gt, &n_eq);
+    const unsigned need = (unsigned)k - n_gt;  // ties to accept, 1 <= need <= n_eq
+    unsigned T2 = 0;                            // accept ties with key2 >= T2
+    if (n_eq > need) {
+        unsigned key2[N + KPT];
+        unsigned mx2 = 0, mn2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int n = 0; n < N + KPT; ++n) {
+            key2[n] = (key[n] == T) ? (0x7FFFFFFFu - (unsigned)doc[n]) : 0u;
+            if (key2[n] != 0) {
+                mx2 = max(mx2, key2[n]);
+                mn2 = min(mn2, key2[n]);
+            }
+        }
+        const SumMaxMin r2 = block_sum_max_min(0u, mx2, mn2, tk.red);
+        unsigned g2, e2;
+        T2 = radix_kth<N + KPT>(key2, need, r2.mx, r2.mn, n_eq, hist, tk.red, &g2, &e2);
+    }
+    if (tid == 0) {
+        tk.count = 0;
+        tk.tau = T;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N + KPT; ++n) {
+        const unsigned x = key[n];
+        const bool take = (x > T) || (x == T && (0x7FFFFFFFu - (unsigned)doc[n]) >= T2);
+        if (x != 0 && take) {
+            const unsigned p = atomicAdd(&tk.count, 1u);
+            tk.bits[p] = x;
+            tk.doc[p] = doc[n];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float load_val(const float *p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float load_val(const __half *p, int64_t i) { return __half2float(p[i]); }
+
+// ------------------------------------------------------------------------------------------------
+// Scoring kernel: one workgroup per (query, split of the doc range).
+// ------------------------------------------------------------------------------------------------
+struct ScoreShared {
+    unsigned tbl[TBL_WORDS];  // hash keys [0,SLOTS) + vals [SLOTS,2*SLOTS)  |  dense acc[G]  |  radix hist
+    TopkShared tk;
+    int64_t m_start[MAXT];  // first posting of term i inside the current unit
+    int m_len[MAXT];        // postings of term i inside the current unit
+    float m_idf[MAXT];
+    float m_qw[MAXT];
+    unsigned short st_term[MAX_STEPS];  // step table of a hash unit: (term, first posting of the 256-chunk)
+    int st_off[MAX_STEPS];
+    int ptile[MAX_TPS + 1];  // overflow packer: postings per tile / group boundaries
+    int grp[MAX_TPS + 1];
+    int n_grp;
+};
+
+// Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
+// scores into the running top-k.  nt = terms in this pass.
+template <typename VT>
+__device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k) {
+    const int tid = threadIdx.x;
+    int *keys = reinterpret_cast<int *>(S.tbl);
+    float *vals = reinterpret_cast<float *>(S.tbl + SLOTS);
+    const int32_t *post_doc = ix.post_doc;
+    const VT *post_val = reinterpret_cast<const VT *>(ix.post_val);
+
+    // step table: term i contributes ceil(len_i / 256) steps
+    const unsigned my_chunks = (tid < nt) ? (unsigned)((my_len + THREADS - 1) / THREADS) : 0u;
+    unsigned n_steps;
+    const unsigned first = block_excl_scan(my_chunks, S.tk.red, &n_steps);
+    for (unsigned c = 0; c < my_chunks; ++c) {
+        S.st_term[first + c] = (unsigned short)tid;
+        S.st_off[first + c] = (int)(c * THREADS);
+    }
+    __syncthreads();
+
+    for (unsigned s0 = 0; s0 < n_steps; s0 += PREFETCH) {
+        int d[PREFETCH];
+        float v[PREFETCH];
+#pragma unroll
+        for (int r = 0; r < PREFETCH; ++r) {
+            const unsigned s = s0 + r;
+            d[r] = -1;
+            v[r] = 0.f;
+            if (s < n_steps) {
+                const int i = S.st_term[s];
+                const int p = S.st_off[s] + tid;
+                if (p < S.m_len[i]) {
+                    const int64_t g = S.m_start[i] + p;
+                    d[r] = post_doc[g];
+                    v[r] = load_val(post_val, g);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PREFETCH; ++r) {
+            const unsigned s = s0 + r;
+            if (s < n_steps) {
+                const int i = S.st_term[s];
+                if (s > 0 && S.st_term[s - 1] != i) __syncthreads();  // next term: order adds per doc
+                if (d[r] >= 0) {
+                    const float c = (v[r] * S.m_idf[i]) * S.m_qw[i];
+                    unsigned h = ((unsigned)d[r] * 0x9E3779B1u) >> (32 - 13);
+                    for (;;) {
+                        const int old = atomicCAS(&keys[h], EMPTY_KEY, d[r]);
+                        if (old == EMPTY_KEY) {
+                            vals[h] = 0.0f + c;
+                            break;
+                        }
+                        if (old == d[r]) {
+                            vals[h] = vals[h] + c;
+                            break;
+                        }
+                        h = (h + 1) & (SLOTS - 1);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // read the table into registers (4 consecutive slots per access), clear the keys behind us
+    unsigned ubits[NPT_HASH];
+    int udoc[NPT_HASH];
+    const unsigned tau = S.tk.tau;
+#pragma unroll
+    for (int j = 0; j < NPT_HASH / 4; ++j) {
+        const int q4 = j * THREADS + tid;
+        const int4 kk = reinterpret_cast<const int4 *>(keys)[q4];
+        const float4 vv = reinterpret_cast<const float4 *>(vals)[q4];
+        reinterpret_cast<int4 *>(keys)[q4] = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+        const int ks[4] = {kk.x, kk.y, kk.z, kk.w};
+        const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned b = __float_as_uint(vs[c]);
+            const bool ok = ks[c] != EMPTY_KEY && vs[c] > 0.0f && b >= tau;
+            ubits[j * 4 + c] = ok ? b : 0u;
+            udoc[j * 4 + c] = ks[c];
+        }
+    }
+    __syncthreads();  // table is free from here: vals region doubles as the radix histogram
+    topk_fold<NPT_HASH>(ubits, udoc, k, S.tk, S.tbl + SLOTS);
+}
+
+// Dense-accumulate one tile of G docs [tile_base, tile_base + G) described by m_start/m_len.
+// first_pass: zero the accumulators; last_pass: select.  (Queries with > MAXT terms take several passes.)
+template <typename VT>
+__device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int nt, int tile_base, bool first_pass) {
+    const int tid = threadIdx.x;
+    float *acc = reinterpret_cast<float *>(S.tbl);
+    const int G = 1 << ix.tile_log2;
+    const int32_t *post_doc = ix.post_doc;
+    const VT *post_val = reinterpret_cast<const VT *>(ix.post_val);
+    if (first_pass) {
+        for (int i = tid; i < G / 4; i += THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    for (int i = 0; i < nt; ++i) {
+        const int len = S.m_len[i];
+        if (len == 0) continue;  // uniform
+        const int64_t start = S.m_start[i];
+        const float idf = S.m_idf[i], qw = S.m_qw[i];
+        for (int p0 = 0; p0 < len; p0 += THREADS * 4) {
+            int d[4];
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + r * THREADS + tid;
+                d[r] = -1;
+                v[r] = 0.f;
+                if (p < len) {
+                    d[r] = post_doc[start + p];
+                    v[r] = load_val(post_val, start + p);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (d[r] >= 0) {
+                    const int o = d[r] - tile_base;
+                    acc[o] = acc[o] + (v[r] * idf) * qw;  // docs unique within a term: no conflict
+                }
+        }
+        __syncthreads();  // next term may touch the same doc
+    }
+}
+
+__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k) {
+    const int tid = threadIdx.x;
+    const float *acc = reinterpret_cast<const float *>(S.tbl);
+    const int G = 1 << ix.tile_log2;
+    unsigned ubits[NPT_DENSE];
+    int udoc[NPT_DENSE];
+    const unsigned tau = S.tk.tau;
+#pragma unroll
+    for (int n = 0; n < NPT_DENSE; ++n) {
+        const int o = n * THREADS + tid;
+        float x = 0.f;
+        if (o < G) x = acc[o];
+        const unsigned b = __float_as_uint(x);
+        const bool ok = x > 0.0f && b >= tau && (int64_t)tile_base + o < ix.n_docs;
+        ubits[n] = ok ? b : 0u;
+        udoc[n] = tile_base + o;
+    }
+    __syncthreads();  // accumulators are in registers; their LDS doubles as the radix histogram
+    topk_fold<NPT_DENSE>(ubits, udoc, k, S.tk, S.tbl);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
+                                                               const int32_t *__restrict__ q_term,
+                                                               const float *__restrict__ q_weight, int nq, int k,
+                                                               int n_splits, int super_log2, int n_super,
+                                                               int32_t *__restrict__ cand_doc,
+                                                               float *__restrict__ cand_score,
+                                                               int32_t *__restrict__ cand_count) {
+    __shared__ ScoreShared S;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / n_splits;
+    const int split = blockIdx.x - q * n_splits;
+    if (q >= nq) return;
+    const int t0 = q_ptr[q];
+    const int nt_all = q_ptr[q + 1] - t0;
+    // this split's supertiles [su_lo, su_hi)
+    const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
+    const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
+    const int tps_log2 = super_log2 - ix.tile_log2;  // tiles per supertile (log2)
+    const int tps = 1 << tps_log2;
+    const int row = ix.n_tiles + 1;
+    int *keys = reinterpret_cast<int *>(S.tbl);
+
+    if (tid == 0) {
+        S.tk.count = 0;
+        S.tk.tau = 0;
+    }
+    for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;
+    __syncthreads();
+
+    const int n_pass = (nt_all + MAXT - 1) / MAXT;  // 1 unless the query has > 256 distinct terms
+
+    if (n_pass == 1 && nt_all > 0) {
+        // ---- fast path: thread i owns term i; unit boundaries are prefetched one unit ahead ----
+        const int nt = nt_all;
+        int term = 0;
+        int64_t base = 0;
+        const int32_t *skip_row = ix.tile_skip;
+        if (tid < nt) {
+            term = q_term[t0 + tid];
+            base = ix.term_ptr[term];
+            skip_row = ix.tile_skip + (int64_t)term * row;
+            S.m_idf[tid] = ix.idf[term];
+            S.m_qw[tid] = q_weight[t0 + tid];
+        }
+        int lo = 0, hi = 0, hi_next = 0;
+        if (tid < nt && su_lo < su_hi) {
+            lo = skip_row[min(su_lo << tps_log2, ix.n_tiles)];
+            hi = skip_row[min((su_lo + 1) << tps_log2, ix.n_tiles)];
+        }
+        for (int su = su_lo; su < su_hi; ++su) {
+            if (tid < nt && su + 1 < su_hi) hi_next = skip_row[min((su + 2) << tps_log2, ix.n_tiles)];
+            const int my_len = (tid < nt) ? hi - lo : 0;
+            const unsigned P = block_sum((unsigned)my_len, S.tk.red);
+            if (P > 0 && P <= (unsigned)HASH_CAP) {
+                if (tid < nt) {
+                    S.m_start[tid] = base + lo;
+                    S.m_len[tid] = my_len;
+                }
+                __syncthreads();
+                hash_unit<VT>(S, ix, nt, my_len, k);
+            } else if (P > 0) {
+                // ---- overflow: pack this supertile's tiles greedily into units of <= HASH_CAP postings;
+                //      a single tile above that is accumulated densely ----
+                const int ja = su << tps_log2;
+                const int jb = min(ja + tps, ix.n_tiles);
+                const int nt_tiles = jb - ja;
+                for (int j = tid; j <= nt_tiles; j += THREADS) S.ptile[j] = 0;
+                __syncthreads();
+                if (tid < nt) {
+                    int prev = skip_row[ja];
+                    for (int j = 0; j < nt_tiles; ++j) {
+                        const int cur = skip_row[ja + j + 1];
+                        if (cur != prev) atomicAdd(&S.ptile[j], cur - prev);
+                        prev = cur;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int ng = 0, acc_p = 0;
+                    S.grp[0] = 0;
+                    for (int j = 0; j < nt_tiles; ++j) {
+                        const int pj = S.ptile[j];
+                        if (acc_p > 0 && acc_p + pj > HASH_CAP) {
+                            S.grp[++ng] = j;
+                            acc_p = 0;
+                        }
+                        acc_p += pj;
+                    }
+                    S.grp[++ng] = nt_tiles;
+                    S.n_grp = ng;
+                }
+                __syncthreads();
+                const int ng = S.n_grp;
+                for (int g = 0; g < ng; ++g) {
+                    const int ga = ja + S.grp[g], gb = ja + S.grp[g + 1];
+                    int glo = 0, ghi = 0;
+                    if (tid < nt) {
+                        glo = skip_row[ga];
+                        ghi = skip_row[gb];
+                    }
+                    const int glen = ghi - glo;
+                    const unsigned GP = block_sum((unsigned)glen, S.tk.red);
+                    if (GP == 0) continue;
+                    if (tid < nt) {
+                        S.m_start[tid] = base + glo;
+                        S.m_len[tid] = glen;
+                    }
+                    __syncthreads();
+                    if (GP <= (unsigned)HASH_CAP) {
+                        hash_unit<VT>(S, ix, nt, glen, k);
+                    } else {  // one dense tile (gb == ga + 1 by construction)
+                        const int tile_base = ga << ix.tile_log2;
+                        dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
+                        dense_tile_select(S, ix, tile_base, k);
+                        for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
+                        __syncthreads();
+                    }
+                }
+            }
+            lo = hi;
+            hi = hi_next;
+        }
+    } else if (nt_all > 0) {
+        // ---- general path (> MAXT query terms): tile by tile, dense accumulators, term passes in
+        //      ascending order so the per-doc summation order is unchanged ----
+        const int ja = su_lo << tps_log2;
+        const int jb = min(su_hi << tps_log2, ix.n_tiles);
+        for (int j = ja; j < jb; ++j) {
+            const int tile_base = j << ix.tile_log2;
+            for (int pass = 0; pass < n_pass; ++pass) {
+                const int nt = min(MAXT, nt_all - pass * MAXT);
+                __syncthreads();
+                if (tid < nt) {
+                    const int term = q_term[t0 + pass * MAXT + tid];
+                    const int32_t *skip_row = ix.tile_skip + (int64_t)term * row;
+                    const int a = skip_row[j], b = skip_row[j + 1];
+                    S.m_start[tid] = ix.term_ptr[term] + a;
+                    S.m_len[tid] = b - a;
+                    S.m_idf[tid] = ix.idf[term];
+                    S.m_qw[tid] = q_weight[t0 + pass * MAXT + tid];
+                }
+                __syncthreads();
+                dense_tile_accumulate<VT>(S, ix, nt, tile_base, pass == 0);
+            }
+            dense_tile_select(S, ix, tile_base, k);
+        }
+    }
+
+    // ---- emit this split's list (unordered; the merge kernel ranks) ----
+    __syncthreads();
+    const unsigned cnt = S.tk.count;
+    const int64_t o = (int64_t)blockIdx.x * k;
+    for (unsigned i = tid; i < cnt; i += THREADS) {
+        cand_doc[o + i] = S.tk.doc[i];
+        cand_score[o + i] = __uint_as_float(S.tk.bits[i]);
+    }
+    if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge kernel: one workgroup per (query, group of lists).  Selects the top-k of up to
+// MERGE_NPT*256 candidates; if `final`, ranks them (bitonic sort on (score desc, doc asc)), adds
+// doc_base and pads the row.
+// ------------------------------------------------------------------------------------------------
+struct MergeShared {
+    TopkShared tk;
+    unsigned hist[RADIX_BINS];
+    unsigned long long sortkey[KMAX];
+    int lstart[64];
+};
+
+__global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__restrict__ in_doc,
+                                                            const float *__restrict__ in_score,
+                                                            const int32_t *__restrict__ in_count, int nq, int n_lists,
+                                                            int k, int lists_per_group, int n_groups, int final_pass,
+                                                            int gathered, int64_t doc_base, int32_t *__restrict__ out_doc,
+                                                            float *__restrict__ out_score,
+                                                            int32_t *__restrict__ out_count) {
+    __shared__ MergeShared M;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / n_groups;
+    const int g = blockIdx.x - q * n_groups;
+    if (q >= nq) return;
+    const int l0 = g * lists_per_group;
+    const int l1 = min(l0 + lists_per_group, n_lists);
+    if (tid == 0) {
+        M.tk.count = 0;
+        M.tk.tau = 0;
+    }
+    __syncthreads();
+    // candidates: flat index c -> (list, rank); lists are dense-packed logically as (l - l0)*k + r
+    unsigned ubits[MERGE_NPT];
+    int udoc[MERGE_NPT];
+    const int span = (l1 - l0) * k;
+#pragma unroll
+    for (int n = 0; n < MERGE_NPT; ++n) {
+        const int c = n * THREADS + tid;
+        ubits[n] = 0;
+        udoc[n] = 0;
+        if (c < span) {
+            const int l = l0 + c / k, r = c - (c / k) * k;
+            // layout 0: [nq][n_lists][k] (+ counts [nq][n_lists]); gathered: [n_lists][nq][k] (+ [n_lists][nq])
+            const int64_t li = gathered ? ((int64_t)l * nq + q) : ((int64_t)q * n_lists + l);
+            const int cnt = in_count[li];
+            if (r < cnt) {
+                const int64_t a = li * k + r;
+                const float s = in_score[a];
+                if (s > 0.0f) {
+                    ubits[n] = __float_as_uint(s);
+                    udoc[n] = in_doc[a];
+                }
+            }
+        }
+    }
+    topk_fold<MERGE_NPT>(ubits, udoc, k, M.tk, M.hist);
+    const unsigned cnt = M.tk.count;
+    if (!final_pass) {
+        const int64_t o = ((int64_t)q * n_groups + g) * k;
+        for (unsigned i = tid; i < cnt; i += THREADS) {
+            out_doc[o + i] = M.tk.doc[i];
+            out_score[o + i] = __uint_as_float(M.tk.bits[i]);
+        }
+        if (tid == 0) out_count[(int64_t)q * n_groups + g] = (int)cnt;
+        return;
+    }
+    // rank: bitonic sort, descending on key64 = score bits : (0x7FFFFFFF - doc)
+    unsigned n = 1;
+    while (n < cnt) n <<= 1;
+    for (unsigned i = tid; i < n; i += THREADS)
+        M.sortkey[i] = i < cnt ? (((unsigned long long)M.tk.bits[i] << 32) | (0x7FFFFFFFu - (unsigned)M.tk.doc[i])) : 0ull;
+    __syncthreads();
+    for (unsigned size = 2; size <= n; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned i = tid; i < (n >> 1); i += THREADS) {
+                const unsigned pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = M.sortkey[pos], b = M.sortkey[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) {
+                    M.sortkey[pos] = b;
+                    M.sortkey[pos + stride] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t o = (int64_t)q * k;
+    for (unsigned i = tid; i < (unsigned)k; i += THREADS) {
+        if (i < cnt) {
+            const unsigned long long x = M.sortkey[i];
+            out_doc[o + i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
+            out_score[o + i] = __uint_as_float((unsigned)(x >> 32));
+        } else {
+            out_doc[o + i] = -1;
+            out_score[o + i] = 0.0f;
+        }
+    }
+    if (tid == 0) out_count[q] = (int)cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index-build kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void srx_impact_kernel(const float *__restrict__ tf, const int32_t *__restrict__ post_doc,
+                                  const float *__restrict__ doc_len, int64_t nnz, float k1f, float bf, float omb,
+                                  float k1p1, float avf, float *__restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+        const float t = tf[p];
+        const float len = doc_len[post_doc[p]];
+        const float norm = k1f * (omb + (bf * len) / avf);  // retrieval.py:58
+        out[p] = (t * k1p1) / (t + norm);                   // retrieval.py:70-72
+    }
+}
+
+__global__ void srx_tile_skip_kernel(const int64_t *__restrict__ term_ptr, const int32_t *__restrict__ post_doc,
+                                     int64_t vocab, int n_tiles, int tile_log2, int32_t *__restrict__ out) {
+    const int64_t total = vocab * (int64_t)(n_tiles + 1);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = e / (n_tiles + 1);
+        const int j = (int)(e - t * (n_tiles + 1));
+        const int64_t b = term_ptr[t], en = term_ptr[t + 1];
+        const int64_t target = (int64_t)j << tile_log2;
+        int64_t lo = b, hi = en;  // lower_bound(post_doc[b..en), target)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)post_doc[mid] < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        out[e] = (int32_t)(lo - b);
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+constexpr int PROF_SLOTS = 256;
+struct srx_index {
+    srx_index_desc d;
+    srx_search_opts opts;
+    hipEvent_t *ev;   // PROF_SLOTS x 3 events (start, after score kernel, after merge kernel), created lazily
+    int ev_n;         // profiled calls recorded since the last srx_profile_read (<= PROF_SLOTS, then it wraps)
+    int64_t ev_calls;
+};
+
+SRX_API int srx_version(void) { return SRX_VERSION; }
+SRX_API const char *srx_last_error(void) { return g_err; }
+
+SRX_API int srx_limits(int32_t *h_out4) {
+    if (!h_out4) return fail(SRX_ERR_INVALID, "srx_limits: null output%s");
+    h_out4[0] = KMAX;
+    h_out4[1] = SRX_MAX_TILE_LOG2;
+    h_out4[2] = HASH_CAP;
+    h_out4[3] = THREADS;
+    return SRX_OK;
+}
+
+SRX_API int srx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(SRX_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+SRX_API int srx_index_create(const srx_index_desc *d, srx_index **out) {
+    if (!d || !out) return fail(SRX_ERR_INVALID, "srx_index_create: null argument%s");
+    if (d->n_docs <= 0 || d->n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_index_create: n_docs out of range%s");
+    if (d->doc_base < 0 || d->doc_base + d->n_docs >= 0x7FFFFFFFll)
+        return fail(SRX_ERR_INVALID, "srx_index_create: doc_base + n_docs must fit int32%s");
+    if (d->vocab <= 0 || d->nnz < 0) return fail(SRX_ERR_INVALID, "srx_index_create: bad vocab / nnz%s");
+    if (d->tile_log2 < 6 || d->tile_log2 > SRX_MAX_TILE_LOG2)
+        return fail(SRX_ERR_INVALID, "srx_index_create: tile_log2 must be in [6, 14]%s");
+    const int64_t nt = (d->n_docs + (1ll << d->tile_log2) - 1) >> d->tile_log2;
+    if (d->n_tiles != nt) return fail(SRX_ERR_INVALID, "srx_index_create: n_tiles != ceil(n_docs / 2^tile_log2)%s");
+    if (d->val_type != SRX_VAL_F32 && d->val_type != SRX_VAL_F16) return fail(SRX_ERR_INVALID, "srx_index_create: bad val_type%s");
+    if (!d->term_ptr || !d->tile_skip || !d->idf || (d->nnz > 0 && (!d->post_doc || !d->post_val)))
+        return fail(SRX_ERR_INVALID, "srx_index_create: null index array%s");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(SRX_ERR_NODEVICE, "srx_index_create: device ordinal not visible%s");
+    srx_index *ix = new (std::nothrow) srx_index();
+    if (!ix) return fail(SRX_ERR_NOMEM, "srx_index_create: host allocation failed%s");
+    ix->d = *d;
+    memset(&ix->opts, 0, sizeof(ix->opts));
+    ix->ev = nullptr;
+    ix->ev_n = 0;
+    ix->ev_calls = 0;
+    *out = ix;
+    return SRX_OK;
+}
+
+SRX_API void srx_index_destroy(srx_index *ix) {
+    if (!ix) return;
+    if (ix->ev) {
+        for (int i = 0; i < 3 * PROF_SLOTS; ++i) (void)hipEventDestroy(ix->ev[i]);
+        delete[] ix->ev;
+    }
+    delete ix;
+}
+
+SRX_API int srx_index_set_opts(srx_index *ix, const srx_search_opts *o) {
+    if (!ix || !o) return fail(SRX_ERR_INVALID, "srx_index_set_opts: null argument%s");
+    if (o->supertile_log2 != 0 && (o->supertile_log2 < ix->d.tile_log2 || o->supertile_log2 > ix->d.tile_log2 + 6))
+        return fail(SRX_ERR_INVALID, "srx_index_set_opts: supertile_log2 must be in [tile_log2, tile_log2+6]%s");
+    if (o->target_blocks < 0) return fail(SRX_ERR_INVALID, "srx_index_set_opts: target_blocks < 0%s");
+    ix->opts = *o;
+    return SRX_OK;
+}
+
+namespace {
+struct Plan {
+    int super_log2, n_super, n_splits;
+};
+
+// Supertile = the doc range one hash unit covers.  Auto rule: the largest power of two (tile .. tile*64)
+// for which an 8-term query of average terms is expected to stay under ~60 % of HASH_CAP.
+Plan make_plan(const srx_index *ix, int nq, int k) {
+    Plan p;
+    const srx_index_desc &d = ix->d;
+    int sl = ix->opts.supertile_log2;
+    if (sl == 0) {
+        const double per_doc_per_term = (double)d.nnz / ((double)d.n_docs * (double)d.vocab);  // E[postings of a term per doc]
+        sl = d.tile_log2;
+        while (sl < d.tile_log2 + 6 && 8.0 * per_doc_per_term * (double)(2ll << sl) <= 0.6 * HASH_CAP) ++sl;
+    }
+    p.super_log2 = sl;
+    p.n_super = (int)((d.n_docs + (1ll << sl) - 1) >> sl);
+    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 2048;
+    int ns = target / (nq > 0 ? nq : 1);
+    if (ns < 1) ns = 1;
+    if (ns > p.n_super) ns = p.n_super;
+    const int cap = (MERGE_NPT * THREADS) / (k > 0 ? k : 1);  // merge kernel takes <= 4096 candidates per group
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    p.n_splits = ns;
+    return p;
+}
+}  // namespace
+
+SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int32_t k) {
+    if (!ix || nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search_workspace_bytes: bad argument%s");
+    const Plan p = make_plan(ix, nq, k);
+    const int64_t lists = (int64_t)nq * p.n_splits;
+    return lists * k * 8 + lists * 4 + 256;
+}
+
+SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                       int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                       int64_t workspace_bytes, void *stream_v) {
+    if (!ix) return fail(SRX_ERR_INVALID, "srx_search: null index%s");
+    if (nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search: need nq >= 0 and 1 <= k <= 1024%s");
+    if (nq == 0) return SRX_OK;
+    if (!q_ptr || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "srx_search: null query / output pointer%s");
+    const int64_t need = srx_search_workspace_bytes(ix, nq, k);
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_search: workspace too small%s");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ix->d.device));
+    const Plan p = make_plan(ix, nq, k);
+    const int64_t lists = (int64_t)nq * p.n_splits;
+    if (lists > 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_search: nq * splits overflows the grid%s");
+    int32_t *cand_doc = (int32_t *)workspace;
+    float *cand_score = (float *)(cand_doc + lists * k);
+    int32_t *cand_count = (int32_t *)(cand_score + lists * k);
+
+    IndexView v;
+    v.term_ptr = ix->d.term_ptr;
+    v.post_doc = ix->d.post_doc;
+    v.post_val = ix->d.post_val;
+    v.tile_skip = ix->d.tile_skip;
+    v.idf = ix->d.idf;
+    v.n_docs = ix->d.n_docs;
+    v.vocab = ix->d.vocab;
+    v.tile_log2 = ix->d.tile_log2;
+    v.n_tiles = ix->d.n_tiles;
+
+    const bool prof = ix->opts.profile != 0;
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        if (!ix->ev) {
+            ix->ev = new (std::nothrow) hipEvent_t[3 * PROF_SLOTS];
+            if (!ix->ev) return fail(SRX_ERR_NOMEM, "srx_search: host allocation failed%s");
+            for (int i = 0; i < 3 * PROF_SLOTS; ++i) HIP_TRY(hipEventCreate(&ix->ev[i]));
+        }
+        ev = ix->ev + 3 * (int)(ix->ev_calls % PROF_SLOTS);
+        HIP_TRY(hipEventRecord(ev[0], stream));
+    }
+    if (ix->d.val_type == SRX_VAL_F32)
+        hipLaunchKernelGGL(srx_score_kernel<float>, dim3((unsigned)lists), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, cand_doc, cand_score, cand_count);
+    else
+        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3((unsigned)lists), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, cand_doc, cand_score, cand_count);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
+    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
+                       p.n_splits, k, p.n_splits, 1, 1, 0, ix->d.doc_base, out_doc, out_score, out_count);
+    HIP_TRY(hipGetLastError());
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        ++ix->ev_calls;
+        if (ix->ev_n < PROF_SLOTS) ++ix->ev_n;
+    }
+    return SRX_OK;
+}
+
+SRX_API int srx_profile_read(srx_index *ix, float *h_ms3) {
+    if (!ix || !h_ms3) return fail(SRX_ERR_INVALID, "srx_profile_read: null argument%s");
+    if (ix->ev_n == 0 || !ix->ev) return fail(SRX_ERR_INVALID, "srx_profile_read: no profiled srx_search has run%s");
+    double acc[3] = {0, 0, 0};
+    for (int i = 0; i < ix->ev_n; ++i) {
+        const int slot = (int)((ix->ev_calls - 1 - i) % PROF_SLOTS);
+        hipEvent_t *ev = ix->ev + 3 * slot;
+        float a = 0, b = 0, c = 0;
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c, ev[0], ev[2]));
+        acc[0] += a;
+        acc[1] += b;
+        acc[2] += c;
+    }
+    for (int j = 0; j < 3; ++j) h_ms3[j] = (float)(acc[j] / ix->ev_n);
+    const int n = ix->ev_n;
+    ix->ev_n = 0;
+    return n;
+}
+
+SRX_API int64_t srx_merge_workspace_bytes(int32_t nq, int32_t n_lists, int32_t k) {
+    if (nq < 0 || n_lists <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_merge_workspace_bytes: bad argument%s");
+    const int fan = (MERGE_NPT * THREADS) / k;
+    if (n_lists <= fan) return 0;
+    // two ping-pong buffers sized for the first reduction level
+    const int64_t g = (n_lists + fan - 1) / fan;
+    return 2 * ((int64_t)nq * g * k * 8 + (int64_t)nq * g * 4 + 256);
+}
+
+SRX_API int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count,
+                           int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
+                           int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (nq < 0 || n_lists <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_merge_topk: bad argument%s");
+    int lay = gathered ? 1 : 0;
+    if (nq == 0) return SRX_OK;
+    if (!in_doc || !in_score || !in_count || !out_doc || !out_score || !out_count)
+        return fail(SRX_ERR_INVALID, "srx_merge_topk: null pointer%s");
+    const int64_t need = srx_merge_workspace_bytes(nq, n_lists, k);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return fail(SRX_ERR_NOMEM, "srx_merge_topk: workspace too small%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int fan = (MERGE_NPT * THREADS) / k;
+    const int32_t *cd = in_doc;
+    const float *cs = in_score;
+    const int32_t *cc = in_count;
+    int lists = n_lists;
+    int level = 0;
+    const int64_t half = need / 2;
+    while (lists > fan) {
+        const int groups = (lists + fan - 1) / fan;
+        char *buf = (char *)workspace + (level & 1) * half;
+        int32_t *od = (int32_t *)buf;
+        float *os = (float *)(od + (int64_t)nq * groups * k);
+        int32_t *oc = (int32_t *)(os + (int64_t)nq * groups * k);
+        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cd, cs, cc,
+                           nq, lists, k, fan, groups, 0, lay, (int64_t)0, od, os, oc);
+        lay = 0;
+        HIP_TRY(hipGetLastError());
+        cd = od;
+        cs = os;
+        cc = oc;
+        lists = groups;
+        ++level;
+    }
+    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cd, cs, cc, nq, lists, k, lists, 1,
+                       1, lay, (int64_t)0, out_doc, out_score, out_count);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
+}
+
+SRX_API int srx_build_impacts(int32_t device, const float *tf, const int32_t *post_doc, const float *doc_len,
+                              int64_t nnz, double k1, double b, double avgdl, float *out_impact, void *stream_v) {
+    if (nnz < 0 || (nnz > 0 && (!tf || !post_doc || !doc_len || !out_impact)))
+        return fail(SRX_ERR_INVALID, "srx_build_impacts: bad argument%s");
+    if (nnz == 0) return SRX_OK;
+    HIP_TRY(hipSetDevice(device));
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(srx_impact_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v, tf, post_doc, doc_len,
+                       nnz, (float)k1, (float)b, (float)(1.0 - b), (float)(k1 + 1.0), (float)avgdl, out_impact);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
+}
+
+SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *post_doc, int64_t vocab,
+                                int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream_v) {
+    if (!term_ptr || !out_skip || vocab <= 0 || n_tiles <= 0 || tile_log2 < 0 || tile_log2 > 30)
+        return fail(SRX_ERR_INVALID, "srx_build_tile_skip: bad argument%s");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t total = vocab * (int64_t)(n_tiles + 1);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(srx_tile_skip_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v, term_ptr, post_doc,
+                       vocab, n_tiles, tile_log2, out_skip);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
+}

@@ -1,0 +1,328 @@
+"""Index construction: the host half mirrors ``RetrievalService.build_bm25_index``
+(/root/reference/rag_system/core/retrieval.py:129-201) bit for bit; the device half turns the doc-major CSR
+into the term-major inverted index + tile skip table that libsparse_rx.so searches (include/sparse_rx.h).
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from collections import Counter
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+
+_TOKEN_RE = re.compile(r"\b\w+\b")
+
+
+def tokenize(text: str) -> List[str]:
+    """``re.findall(r'\\b\\w+\\b', text.lower())`` -- retrieval.py:148 / :236 (Unicode ``\\w``, str.lower())."""
+    return _TOKEN_RE.findall(text.lower())
+
+
+@dataclass
+class HostIndex:
+    """The state ``build_bm25_index`` leaves on the reference object (retrieval.py:110-117)."""
+    indptr: np.ndarray        # int32/int64 [n_docs+1]
+    indices: np.ndarray       # int32 [nnz], sorted per row
+    data: np.ndarray          # float32 [nnz] term counts (or learned weights)
+    doc_lengths: np.ndarray   # float32 [n_docs]
+    idf: np.ndarray           # float32 [vocab]
+    avgdl: float
+    vocabulary: Dict[str, int]
+    doc_ids: List[str]
+
+    @property
+    def n_docs(self) -> int:
+        return len(self.indptr) - 1
+
+    @property
+    def vocab_size(self) -> int:
+        return len(self.idf)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indptr[-1])
+
+
+def bm25_idf(df: np.ndarray, n_docs: int) -> np.ndarray:
+    """``np.log((N - df + 0.5) / (df + 0.5)).astype(np.float32)`` -- retrieval.py:187-189 (f64 log, cast)."""
+    return np.log((n_docs - df + 0.5) / (df + 0.5)).astype(np.float32)
+
+
+def tfidf_idf(df: np.ndarray, n_docs: int) -> np.ndarray:
+    """``np.log(N / (df + 1)).astype(np.float32)`` -- evaluate_rag_pipeline.py:273-278."""
+    return np.log(n_docs / (df + 1)).astype(np.float32)
+
+
+def build_host_index(corpus: Dict[str, Dict], idf_kind: str = "bm25") -> HostIndex:
+    """Tokenise, sorted vocabulary, CSR f32, doc lengths, idf, avgdl -- retrieval.py:129-201, same order of
+    operations so every array is bit-equal to the reference's (pinned by tests/golden/text_small.npz)."""
+    from scipy.sparse import csr_matrix
+
+    if not corpus:
+        raise ValueError("Empty corpus provided")  # retrieval.py:133-134
+    doc_ids = list(corpus.keys())  # row order = dict insertion order (:141)
+    doc_tokens: List[List[str]] = []
+    vocab_set = set()
+    for doc_id in doc_ids:
+        doc = corpus[doc_id]
+        text = doc.get("text", doc.get("content", doc.get("body", "")))  # :145 (title is never indexed)
+        if text:
+            toks = tokenize(text)
+            doc_tokens.append(toks)
+            vocab_set.update(toks)
+        else:
+            doc_tokens.append([])
+    vocabulary = {term: idx for idx, term in enumerate(sorted(vocab_set))}  # :155 code-point order
+    n_docs, V = len(doc_tokens), len(vocabulary)
+    doc_lengths = np.zeros(n_docs, dtype=np.float32)
+    rows: List[int] = []
+    cols: List[int] = []
+    data: List[float] = []
+    for i, toks in enumerate(doc_tokens):
+        doc_lengths[i] = len(toks)  # :165 token count incl. repeats
+        if toks:
+            for term, cnt in Counter(toks).items():
+                rows.append(i)
+                cols.append(vocabulary[term])
+                data.append(float(cnt))
+    m = csr_matrix((data, (rows, cols)), shape=(n_docs, V), dtype=np.float32)  # :176-180
+    m.sort_indices()
+    m.eliminate_zeros()
+    df = np.bincount(m.indices, minlength=V)  # :187
+    idf = bm25_idf(df, n_docs) if idf_kind == "bm25" else tfidf_idf(df, n_docs)
+    avgdl = float(np.mean(doc_lengths))  # :190 (np.mean of f32 -> f32-precision value)
+    return HostIndex(indptr=m.indptr, indices=m.indices, data=m.data, doc_lengths=doc_lengths, idf=idf, avgdl=avgdl,
+                     vocabulary=vocabulary, doc_ids=doc_ids)
+
+
+def encode_queries(texts: Sequence[str], vocabulary: Dict[str, int]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Query texts -> CSR batch (q_ptr i32, q_term i32 ascending unique, q_weight f32 = term count).
+    Mirrors retrieval.py:236-252: tokenise, Counter, OOV dropped; a query with no in-vocabulary term gets an
+    empty row (the reference returns {} for it)."""
+    q_ptr = np.zeros(len(texts) + 1, dtype=np.int32)
+    terms: List[np.ndarray] = []
+    weights: List[np.ndarray] = []
+    for i, text in enumerate(texts):
+        cnt = Counter(tokenize(text)) if text else {}
+        pairs = sorted((vocabulary[t], float(c)) for t, c in cnt.items() if t in vocabulary)
+        q_ptr[i + 1] = q_ptr[i] + len(pairs)
+        if pairs:
+            terms.append(np.fromiter((p[0] for p in pairs), dtype=np.int32, count=len(pairs)))
+            weights.append(np.fromiter((p[1] for p in pairs), dtype=np.float32, count=len(pairs)))
+    q_term = np.concatenate(terms) if terms else np.zeros(0, dtype=np.int32)
+    q_weight = np.concatenate(weights) if weights else np.zeros(0, dtype=np.float32)
+    return q_ptr, q_term, q_weight
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device index
+# ---------------------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t) -> int:
+    return 0 if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream_ptr(torch, device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DeviceIndex:
+    """One doc-range shard resident in HBM: term-major postings + tile skip table + idf, plus the
+    ``srx_index`` handle.  All tensors are owned here (PyTorch-ROCm is the allocator); the library only
+    keeps pointers."""
+
+    def __init__(self, term_ptr, post_doc, post_val, tile_skip, idf, n_docs: int, vocab: int, doc_base: int,
+                 tile_log2: int, device):
+        torch = _torch()
+        self.device = torch.device(device)
+        self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf = term_ptr, post_doc, post_val, tile_skip, idf
+        self.n_docs, self.vocab, self.doc_base, self.tile_log2 = int(n_docs), int(vocab), int(doc_base), int(tile_log2)
+        self.n_tiles = (self.n_docs + (1 << tile_log2) - 1) >> tile_log2
+        self.nnz = int(post_doc.numel())
+        self.val_type = _capi.SRX_VAL_F16 if post_val.dtype == torch.float16 else _capi.SRX_VAL_F32
+        d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
+                            nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
+                            term_ptr=_ptr(term_ptr), post_doc=_ptr(post_doc), post_val=_ptr(post_val),
+                            tile_skip=_ptr(tile_skip), idf=_ptr(idf))
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
+        self._h = h
+        self._ws = None
+        self._opts = _capi.SearchOpts()
+
+    # -- construction ----------------------------------------------------------------------------------
+    @classmethod
+    def from_csr(cls, indptr, indices, data, idf, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
+                 avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
+                 tile_log2: int = 14) -> "DeviceIndex":
+        """Build from a doc-major CSR (host numpy or device torch arrays).
+
+        mode "bm25": post_val = impact(tf, len) precomputed in fp32 (retrieval.py:58,70-71), idf as given.
+        mode "dot" : post_val = data (optionally fp16), contribution data*idf*qw (evaluate_rag_pipeline.py:117).
+        """
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.SparseRxUnavailable("no HIP device visible: DeviceIndex needs a GPU (there is no CPU fallback)")
+        dev = torch.device(device)
+        L = _capi.lib()
+
+        def to_dev(x, dtype):
+            if isinstance(x, torch.Tensor):
+                return x.to(device=dev, dtype=dtype)
+            return torch.as_tensor(np.ascontiguousarray(x), device=dev).to(dtype)
+
+        with torch.cuda.device(dev):
+            indptr_d = to_dev(indptr, torch.int64)
+            cols = to_dev(indices, torch.int32)
+            vals = to_dev(data, torch.float32)
+            n_docs = indptr_d.numel() - 1
+            counts = indptr_d[1:] - indptr_d[:-1]
+            rows = torch.repeat_interleave(torch.arange(n_docs, device=dev, dtype=torch.int32), counts)
+            dl = None if doc_lengths is None else to_dev(doc_lengths, torch.float32)
+            return cls.from_coo(rows, cols, vals, to_dev(idf, torch.float32), n_docs, doc_lengths=dl, k1=k1, b=b,
+                                avgdl=avgdl, mode=mode, val_dtype=val_dtype, device=dev, doc_base=doc_base,
+                                tile_log2=tile_log2)
+
+    @classmethod
+    def from_coo(cls, rows, cols, vals, idf, n_docs: int, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
+                 avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
+                 tile_log2: int = 14) -> "DeviceIndex":
+        """Build from device COO triples sorted by (row, col) -- i.e. the CSR's nnz order with explicit rows
+        (rows i32 shard-local, cols i32, vals f32).  CSR -> CSC is one stable sort by term, which keeps rows
+        ascending inside a term."""
+        torch = _torch()
+        dev = torch.device(device)
+        L = _capi.lib()
+        with torch.cuda.device(dev):
+            idf_d = idf.to(device=dev, dtype=torch.float32).contiguous()
+            V = idf_d.numel()
+            nnz = cols.numel()
+            if nnz > 0:
+                df = torch.bincount(cols, minlength=V)
+                _, perm = torch.sort(cols, stable=True)
+                post_doc = rows[perm].contiguous()
+                tf = vals[perm].contiguous()
+                del perm
+            else:
+                post_doc = torch.zeros(0, dtype=torch.int32, device=dev)
+                tf = torch.zeros(0, dtype=torch.float32, device=dev)
+                df = torch.zeros(V, dtype=torch.int64, device=dev)
+            term_ptr = torch.zeros(V + 1, dtype=torch.int64, device=dev)
+            term_ptr[1:] = torch.cumsum(df, 0)
+            stream = _stream_ptr(torch, dev)
+            if mode == "bm25":
+                if doc_lengths is None:
+                    raise ValueError("mode='bm25' needs doc_lengths")
+                dl = doc_lengths.to(device=dev, dtype=torch.float32).contiguous()
+                post_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+                _capi.check(L.srx_build_impacts(dev.index or 0, _ptr(tf), _ptr(post_doc), _ptr(dl), nnz, float(k1), float(b),
+                                                float(avgdl), _ptr(post_val), stream), "srx_build_impacts")
+                torch.cuda.synchronize(dev)
+                del tf
+            elif mode == "dot":
+                post_val = tf.to(torch.float16) if val_dtype == "f16" else tf
+            else:
+                raise ValueError(f"unknown mode {mode!r}")
+            n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
+            tile_skip = torch.empty(V * (n_tiles + 1), dtype=torch.int32, device=dev)
+            _capi.check(L.srx_build_tile_skip(dev.index or 0, _ptr(term_ptr), _ptr(post_doc), V, n_tiles, tile_log2,
+                                              _ptr(tile_skip), stream), "srx_build_tile_skip")
+            torch.cuda.synchronize(dev)
+        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev)
+
+    @classmethod
+    def from_host_index(cls, hi: HostIndex, k1: float = 1.2, b: float = 0.75, **kw) -> "DeviceIndex":
+        return cls.from_csr(hi.indptr, hi.indices, hi.data, hi.idf, doc_lengths=hi.doc_lengths, k1=k1, b=b,
+                            avgdl=hi.avgdl, **kw)
+
+    # -- search ----------------------------------------------------------------------------------------
+    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False) -> None:
+        self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile))
+        _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
+
+    def workspace_bytes(self, nq: int, k: int) -> int:
+        return _capi.check(_capi.lib().srx_search_workspace_bytes(self._h, nq, k), "srx_search_workspace_bytes")
+
+    def search_device(self, q_ptr, q_term, q_weight, k: int, out=None):
+        """Batched search on device tensors (q_ptr i32[nq+1], q_term i32, q_weight f32).
+        Returns (doc i32[nq,k], score f32[nq,k], count i32[nq]) device tensors; asynchronous on the current stream."""
+        torch = _torch()
+        nq = q_ptr.numel() - 1
+        if not (1 <= k <= _capi.limits()["max_k"]):
+            raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = (torch.empty((nq, k), dtype=torch.int32, device=self.device),
+                       torch.empty((nq, k), dtype=torch.float32, device=self.device),
+                       torch.empty((nq,), dtype=torch.int32, device=self.device))
+            need = self.workspace_bytes(nq, k)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            rc = _capi.lib().srx_search(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out[0]), _ptr(out[1]),
+                                        _ptr(out[2]), _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+            _capi.check(rc, "srx_search")
+        return out
+
+    def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
+        """Host arrays in, host arrays out (doc, score, count)."""
+        torch = _torch()
+        nq = len(q_ptr) - 1
+        if nq == 0:
+            return (np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), np.zeros(0, np.int32))
+        dev = self.device
+        qp = torch.as_tensor(np.ascontiguousarray(q_ptr, dtype=np.int32), device=dev)
+        qt = torch.as_tensor(np.ascontiguousarray(q_term, dtype=np.int32), device=dev)
+        qw = torch.as_tensor(np.ascontiguousarray(q_weight, dtype=np.float32), device=dev)
+        d, s, c = self.search_device(qp, qt, qw, k)
+        torch.cuda.synchronize(dev)
+        return d.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+
+    def profile_read(self):
+        """Average kernel durations (ms) over the profiled searches since the last read."""
+        ms = (ctypes.c_float * 3)()
+        n = _capi.check(_capi.lib().srx_profile_read(self._h, ms), "srx_profile_read")
+        return {"score_ms": ms[0], "merge_ms": ms[1], "total_ms": ms[2], "calls": n}
+
+    def device_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib().srx_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_device(in_doc, in_score, in_count, k: int, gathered: bool = False):
+    """``srx_merge_topk`` on device tensors.  gathered=False: in_doc/in_score [nq, n_lists, k], in_count
+    [nq, n_lists]; gathered=True: [n_lists, nq, k] / [n_lists, nq] (the all-gather layout)."""
+    torch = _torch()
+    if gathered:
+        n_lists, nq = in_count.shape
+    else:
+        nq, n_lists = in_count.shape
+    dev = in_doc.device
+    L = _capi.lib()
+    with torch.cuda.device(dev):
+        out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+               torch.empty((nq,), dtype=torch.int32, device=dev))
+        need = _capi.check(L.srx_merge_workspace_bytes(nq, n_lists, k), "srx_merge_workspace_bytes")
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        in_doc, in_score, in_count = in_doc.contiguous(), in_score.contiguous(), in_count.contiguous()
+        rc = L.srx_merge_topk(dev.index or 0, _ptr(in_doc), _ptr(in_score), _ptr(in_count), nq, n_lists, k, int(gathered),
+                              _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream_ptr(torch, dev))
+        _capi.check(rc, "srx_merge_topk")
+    return out

@@ -1,0 +1,178 @@
+"""Drop-in mirror of the reference's ``RetrievalService`` BM25 API
+(/root/reference/rag_system/core/retrieval.py:95-506) running on the MI355X HIP engine.
+
+Same names, argument meaning, result shape and error behaviour for the hot path:
+``build_bm25_index(corpus)`` (:129), ``search_bm25(queries, top_k)`` (:203), ``get_stats()`` (:471),
+``clear_cache()`` (:464), ``close()`` / context manager (:495-506).  The document store (MemoryIndex) and the
+dense ``search_by_vector`` side are outside this build's scope.
+
+What changes underneath: ``search_bm25`` scores the WHOLE query dict as one batch through
+``srx_search`` (libsparse_rx.so) instead of looping ``simd_bm25_score`` + ``fast_topk_selection`` per query
+(:210-229, :256-284).  There is no CPU fallback: without the HIP library / a GPU the calls raise.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from .index import DeviceIndex, HostIndex, build_host_index, encode_queries
+
+logger = logging.getLogger(__name__)
+
+NUMBA_AVAILABLE = False  # kept for get_stats() key compatibility (retrieval.py:476)
+
+
+class RetrievalService:
+    """BM25 retrieval with the reference's API; scoring + top-k run on the GPU."""
+
+    def __init__(self, index_path=None, embedding_path=None, num_workers: int = 4, cache_size: int = 1000, *,
+                 device: str = "cuda:0", tile_log2: int = 14, **compat_kwargs):
+        # index_path / embedding_path / num_workers are accepted for signature compatibility (retrieval.py:98-102);
+        # README-only kwargs (use_simd, batch_size, monitor, ...) are swallowed.
+        self.index_path = index_path
+        self.embedding_path = embedding_path
+        self.num_workers = num_workers
+        self.cache_size = cache_size
+        self.logger = logger
+        self.device = device
+        self.tile_log2 = tile_log2
+        self.host: Optional[HostIndex] = None
+        self.dev: Optional[DeviceIndex] = None
+        self.k1: float = 1.2   # retrieval.py:116
+        self.b: float = 0.75   # retrieval.py:117
+        self._built_k1b: Optional[Tuple[float, float]] = None
+        self.query_cache: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+        self.cache_lock = threading.RLock()
+        self.build_time = 0.0
+
+    # -- reference attribute names (read-only views) -----------------------------------------------------
+    @property
+    def vocabulary(self) -> Dict[str, int]:
+        return self.host.vocabulary if self.host else {}
+
+    @property
+    def doc_ids(self) -> List[str]:
+        return self.host.doc_ids if self.host else []
+
+    @property
+    def idf_weights(self):
+        return self.host.idf if self.host else None
+
+    @property
+    def doc_lengths(self):
+        return self.host.doc_lengths if self.host else None
+
+    @property
+    def avgdl(self) -> float:
+        return self.host.avgdl if self.host else 0.0
+
+    @property
+    def corpus_tf(self):
+        if self.host is None:
+            return None
+        from scipy.sparse import csr_matrix
+        h = self.host
+        return csr_matrix((h.data, h.indices, h.indptr), shape=(h.n_docs, h.vocab_size))
+
+    # -- build ------------------------------------------------------------------------------------------
+    def build_bm25_index(self, corpus: Dict[str, Dict]) -> None:
+        """retrieval.py:129-201 on the host (bit-equal arrays), then the device inverted index."""
+        t0 = time.perf_counter()
+        self.host = build_host_index(corpus, idf_kind="bm25")
+        self._upload()
+        self.build_time = time.perf_counter() - t0
+        self.logger.info("BM25 index built in %.2fs (%d docs, %d terms, %d postings)", self.build_time,
+                         self.host.n_docs, self.host.vocab_size, self.host.nnz)
+
+    def _upload(self) -> None:
+        if self.dev is not None:
+            self.dev.close()
+        self.dev = DeviceIndex.from_host_index(self.host, k1=self.k1, b=self.b, device=self.device,
+                                               tile_log2=self.tile_log2)
+        self._built_k1b = (self.k1, self.b)
+        with self.cache_lock:
+            self.query_cache.clear()
+
+    # -- search -----------------------------------------------------------------------------------------
+    def search_bm25(self, queries: Dict[str, str], top_k: int = 10) -> Dict[str, Dict[str, float]]:
+        """retrieval.py:203-231 semantics; one batched GPU call for all uncached queries."""
+        if self.host is None:
+            raise ValueError("BM25 index not built. Call build_bm25_index() first.")  # :205-206
+        if (self.k1, self.b) != self._built_k1b:
+            self._upload()  # k1 / b are plain attributes on the reference (:116-117): impacts depend on them
+        results: Dict[str, Dict[str, float]] = {}
+        pending: Dict[str, List[str]] = {}  # cache_key -> qids waiting for it
+        texts: List[str] = []
+        keys: List[str] = []
+        for qid, text in queries.items():
+            if not text or not text.strip():  # :211-213
+                results[qid] = {}
+                continue
+            key = f"{text.strip()}:{top_k}"  # :216
+            with self.cache_lock:
+                hit = self.query_cache.get(key)
+            if hit is not None:
+                results[qid] = self._to_dict(*hit)
+                continue
+            results[qid] = {}  # keeps the caller's qid order; filled below
+            if key not in pending:
+                pending[key] = []
+                texts.append(text)
+                keys.append(key)
+            pending[key].append(qid)
+        if texts:
+            q_ptr, q_term, q_weight = encode_queries(texts, self.host.vocabulary)
+            k_eff = min(int(top_k), self.host.n_docs)  # k >= n_docs -> everything, ranked (:281-284)
+            docs, scores, counts = self.dev.search(q_ptr, q_term, q_weight, k_eff)
+            for i, key in enumerate(keys):
+                if q_ptr[i + 1] == q_ptr[i]:  # no token / no in-vocabulary term -> {} and nothing cached (:237-238, :251-252)
+                    continue
+                c = int(counts[i])
+                entry = (docs[i, :c].astype(np.int64), scores[i, :c].copy())
+                with self.cache_lock:
+                    if len(self.query_cache) < 1000:  # :288
+                        self.query_cache[key] = entry
+                d = self._to_dict(*entry)
+                for qid in pending[key]:
+                    results[qid] = dict(d)
+        return results
+
+    def _to_dict(self, idx: np.ndarray, sc: np.ndarray) -> Dict[str, float]:
+        ids = self.host.doc_ids
+        return {ids[int(i)]: float(s) for i, s in zip(idx, sc) if s > 0}  # :292-296
+
+    # -- misc -------------------------------------------------------------------------------------------
+    def clear_cache(self) -> None:
+        with self.cache_lock:
+            self.query_cache.clear()
+
+    def get_stats(self) -> Dict[str, object]:
+        """Same keys as retrieval.py:471-493, plus backend facts."""
+        stats: Dict[str, object] = {"cache_size": 0, "query_cache_size": len(self.query_cache),
+                                    "numba_available": NUMBA_AVAILABLE, "backend": "hip-gfx950"}
+        if self.host is not None:
+            h = self.host
+            density = h.nnz / (h.n_docs * h.vocab_size)
+            memory_mb = (h.data.nbytes + h.indices.nbytes + h.indptr.nbytes) / (1024 * 1024)
+            stats.update({"num_docs": h.n_docs, "vocab_size": h.vocab_size, "matrix_density": density,
+                          "bm25_memory_mb": memory_mb, "avgdl": h.avgdl})
+        if self.dev is not None:
+            stats["device_index_mb"] = self.dev.device_bytes() / (1024 * 1024)
+        return stats
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.close()
+
+    def close(self) -> None:
+        if self.dev is not None:
+            self.dev.close()
+            self.dev = None
+        self.clear_cache()

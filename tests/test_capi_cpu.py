@@ -1,0 +1,99 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sparse_rx.h declares (no compute
+calls without a GPU), argument validation that does not touch the device, and the host logic."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sparse_rx
+from sparse_rx import _capi
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sparse_rx.h")).read()
+    declared = set(re.findall(r"\b(srx_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libsparse_rx.so does not export {name}"
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    assert L.srx_version() == 100
+
+
+def test_limits_and_error_strings():
+    lim = _capi.limits()
+    assert lim == {"max_k": 1024, "max_tile_log2": 14, "hash_cap": 4096, "threads": 256}
+    L = _capi.lib()
+    assert L.srx_index_create(None, None) == -1
+    assert b"null" in L.srx_last_error()
+    assert L.srx_search(None, None, None, None, 1, 10, None, None, None, None, 0, None) == -1
+    with pytest.raises(ValueError):
+        _capi.check(L.srx_merge_workspace_bytes(1, 0, 10), "srx_merge_workspace_bytes")
+    assert L.srx_merge_workspace_bytes(10, 8, 100) == 0        # 800 candidates fit one workgroup
+    assert L.srx_merge_workspace_bytes(10, 8, 1000) > 0        # 8000 do not: tree merge needs scratch
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sparse_rx.SparseRxUnavailable):
+        sparse_rx.DeviceIndex.from_csr(np.array([0, 1]), np.array([0], np.int32), np.array([1.0], np.float32),
+                                       np.array([1.0], np.float32), doc_lengths=np.array([1.0], np.float32))
+    svc = sparse_rx.RetrievalService()
+    with pytest.raises(ValueError, match="BM25 index not built"):
+        svc.search_bm25({"a": "b"})
+    with pytest.raises(ValueError, match="Empty corpus"):
+        svc.build_bm25_index({})
+    with pytest.raises(sparse_rx.SparseRxUnavailable):
+        svc.build_bm25_index({"d": {"text": "hello world"}})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.dirname(os.path.abspath(sparse_rx._capi.__file__))
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, fn), encoding="utf-8").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f"{fn} imports oracle"
+                assert "liboracle" not in src, f"{fn} references liboracle"
+
+
+def test_host_index_matches_reference_state(golden_dir):
+    """build_host_index == the state RetrievalService.build_bm25_index left on the reference (bit-equal)."""
+    z = np.load(os.path.join(golden_dir, "text_small.npz"))
+    j = json.load(open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8"))
+    h = sparse_rx.build_host_index(j["corpus"])
+    assert h.doc_ids == list(z["doc_ids"])
+    assert [t for t, _ in sorted(h.vocabulary.items(), key=lambda kv: kv[1])] == list(z["vocabulary"])
+    assert np.array_equal(h.indptr, z["tf_indptr"]) and np.array_equal(h.indices, z["tf_indices"])
+    assert np.array_equal(h.data, z["tf_data"]) and h.data.dtype == np.float32
+    assert np.array_equal(h.doc_lengths, z["doc_lengths"])
+    assert np.array_equal(h.idf.view(np.uint32), z["idf"].view(np.uint32))
+    assert h.avgdl == float(z["avgdl"])
+
+
+def test_encode_queries_matches_reference_query_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "text_small.npz"))
+    j = json.load(open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8"))
+    h = sparse_rx.build_host_index(j["corpus"])
+    qids = list(z["score_qids"])
+    q_ptr, q_term, q_w = sparse_rx.encode_queries([j["queries"][q] for q in qids], h.vocabulary)
+    assert np.array_equal(q_ptr, z["score_q_ptr"]) and np.array_equal(q_term, z["score_q_term"])
+    assert np.array_equal(q_w, z["score_q_weight"])
+    # blank / OOV-only / punctuation-only queries encode to empty rows (the reference returns {} for them)
+    p, t, w = sparse_rx.encode_queries(["", "   ", "zzzunknown qqqmissing", "?!", "w5 notaword w6"], h.vocabulary)
+    assert list(np.diff(p)) == [0, 0, 0, 0, 2]
+
+
+def test_tokenizer_cases():
+    """Probed behaviour of re.findall(r'\\b\\w+\\b', text.lower())."""
+    tk = sparse_rx.tokenize
+    assert tk("Don't") == ["don", "t"]
+    assert tk("U.S.A.") == ["u", "s", "a"]
+    assert tk("3.14") == ["3", "14"]
+    assert tk("café_1") == ["café_1"]
+    assert tk("") == []

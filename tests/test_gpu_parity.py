@@ -1,0 +1,297 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, libsparse_rx.so) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at larger sizes -- through size-independent
+properties.  Bar: doc ids and fp32 score bits EXACTLY equal to the oracle (same canonical tie order: score desc,
+doc asc); against reference-produced fixtures, equal modulo the reference's unspecified order inside exact ties
+(tests/parity.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (checker only)
+from parity import assert_canonical_order, assert_ranked_equal  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rx():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import sparse_rx
+    sparse_rx._capi.lib()  # fails loudly if the HIP library is missing
+    return sparse_rx
+
+
+def _oracle_batch(c, idf, avgdl, q, k, mode=oracle.MODE_BM25_F32, k1=1.2, b=0.75):
+    return oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf, q[0], q[1], q[2], k, k1, b, avgdl, mode=mode)
+
+
+def _assert_exact(got, exp, label=""):
+    gd, gs, gc = got
+    ed, es, ec = exp
+    assert np.array_equal(gc, ec), f"{label}: counts differ at {np.flatnonzero(gc != ec)[:8]}: {gc[gc != ec][:8]} vs {ec[gc != ec][:8]}"
+    bad = np.flatnonzero((gs.view(np.uint32) != es.view(np.uint32)).any(axis=1) | (gd != ed).any(axis=1))
+    if len(bad):
+        q = bad[0]
+        j = np.flatnonzero((gd[q] != ed[q]) | (gs[q].view(np.uint32) != es[q].view(np.uint32)))[:5]
+        raise AssertionError(f"{label}: {len(bad)} queries differ; first q={q} ranks {j}: got {gd[q][j]} {gs[q][j]} exp {ed[q][j]} {es[q][j]}")
+
+
+def _dev_index(rx, c, idf, avgdl, **kw):
+    return rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, doc_lengths=c.doc_lengths, avgdl=avgdl, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden fixtures produced by the reference
+# ---------------------------------------------------------------------------------------------------------------
+def test_text_golden_end_to_end(rx, golden_dir):
+    z = np.load(os.path.join(golden_dir, "text_small.npz"))
+    with open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8") as f:
+        j = json.load(f)
+    svc = rx.RetrievalService(device="cuda:0", tile_log2=6)
+    with pytest.raises(ValueError, match="BM25 index not built"):
+        svc.search_bm25({"q": "x"})
+    with pytest.raises(ValueError, match="Empty corpus"):
+        svc.build_bm25_index({})
+    svc.build_bm25_index(j["corpus"])
+    # host index state is bit-equal to the reference's
+    assert svc.doc_ids == list(z["doc_ids"])
+    assert [t for t, _ in sorted(svc.vocabulary.items(), key=lambda kv: kv[1])] == list(z["vocabulary"])
+    assert np.array_equal(svc.host.indptr, z["tf_indptr"]) and np.array_equal(svc.host.indices, z["tf_indices"])
+    assert np.array_equal(svc.host.data, z["tf_data"]) and np.array_equal(svc.host.doc_lengths, z["doc_lengths"])
+    assert np.array_equal(svc.host.idf.view(np.uint32), z["idf"].view(np.uint32))
+    assert svc.avgdl == float(z["avgdl"])
+    row = {d: i for i, d in enumerate(svc.doc_ids)}
+    qids = list(z["score_qids"])
+    for k in ("3", "10", "1000"):
+        svc.clear_cache()
+        got = svc.search_bm25(j["queries"], top_k=int(k))
+        exp = j["results"][k]
+        assert list(got.keys()) == list(exp.keys())
+        for qid in exp:
+            g, e = got[qid], exp[qid]
+            full = z["full_scores"][qids.index(qid)] if qid in qids else None
+            assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                                np.array(list(e.values()), np.float32), k=min(int(k), len(row)), full_scores=full,
+                                label=f"k={k} {qid}")
+        again = svc.search_bm25(j["queries"], top_k=int(k))  # cache-hit path
+        assert again == got
+    st = svc.get_stats()
+    for key in ("cache_size", "query_cache_size", "numba_available", "num_docs", "vocab_size", "matrix_density",
+                "bm25_memory_mb", "avgdl"):
+        assert key in st
+    assert st["num_docs"] == j["stats"]["num_docs"] and st["vocab_size"] == j["stats"]["vocab_size"]
+    svc.close()
+
+
+@pytest.mark.parametrize("tile_log2,super_log2,target_blocks", [(6, 0, 0), (8, 8, 4096), (7, 11, 1), (14, 0, 0)])
+def test_csr_zipf_golden(rx, golden_dir, tile_log2, super_log2, target_blocks):
+    z = np.load(os.path.join(golden_dir, "csr_zipf.npz"))
+    ix = rx.DeviceIndex.from_csr(z["tf_indptr"], z["tf_indices"], z["tf_data"], z["idf"], doc_lengths=z["doc_lengths"],
+                                 k1=float(z["k1"]), b=float(z["b"]), avgdl=float(z["avgdl"]), tile_log2=tile_log2)
+    ix.set_opts(supertile_log2=super_log2, target_blocks=target_blocks)
+    for k in (10, 100):
+        gd, gs, gc = ix.search(z["q_ptr"], z["q_term"], z["q_weight"], k)
+        ed, es, ec = z[f"top{k}_doc"], z[f"top{k}_score"], z[f"top{k}_count"]
+        assert np.array_equal(gc, ec)
+        for q in range(len(gc)):
+            lo, hi = z["q_ptr"][q], z["q_ptr"][q + 1]
+            full = oracle.bm25_scores(z["tf_indptr"], z["tf_indices"], z["tf_data"], z["doc_lengths"], z["idf"],
+                                      z["q_term"][lo:hi], z["q_weight"][lo:hi], float(z["k1"]), float(z["b"]), float(z["avgdl"]))
+            c = gc[q]
+            assert_ranked_equal(gd[q, :c], gs[q, :c], ed[q, :c], es[q, :c], k=k, full_scores=full, label=f"k={k} q{q}")
+            assert_canonical_order(gd[q, :c], gs[q, :c])
+            assert np.all(gd[q, c:] == -1) and np.all(gs[q, c:] == 0)
+        exp = oracle.search_batch(z["tf_indptr"], z["tf_indices"], z["tf_data"], z["doc_lengths"], z["idf"], z["q_ptr"],
+                                  z["q_term"], z["q_weight"], k, float(z["k1"]), float(z["b"]), float(z["avgdl"]))
+        _assert_exact((gd, gs, gc), exp, f"zipf k={k}")
+    ix.close()
+
+
+def test_tfidf_dot_mode_golden(rx, golden_dir):
+    """simd_tfidf_score twin (evaluate_rag_pipeline.py:95-121): dot mode with idf = log(N/(df+1))."""
+    z = np.load(os.path.join(golden_dir, "csr_zipf.npz"))
+    ix = rx.DeviceIndex.from_csr(z["tf_indptr"], z["tf_indices"], z["tf_data"], z["idf_tfidf"], mode="dot", tile_log2=8)
+    n = z["tfidf_full"].shape[0]
+    k = 50
+    gd, gs, gc = ix.search(z["q_ptr"][: n + 1], z["q_term"][: z["q_ptr"][n]], z["q_weight"][: z["q_ptr"][n]], k)
+    for q in range(n):
+        full = z["tfidf_full"][q]  # produced by the reference
+        idx, sc = oracle.topk(full, k)
+        keep = sc > 0
+        c = gc[q]
+        assert c == keep.sum()
+        assert np.array_equal(gd[q, :c], idx[keep]) and np.array_equal(gs[q, :c].view(np.uint32), sc[keep].view(np.uint32))
+    ix.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# seeded synthetic corpora vs the oracle (exact)
+# ---------------------------------------------------------------------------------------------------------------
+def test_uniform_sparse_hash_path(rx):
+    """C2-shaped, scaled down: every unit goes through the LDS hash path; several splits; k=100."""
+    from sparse_rx import synth
+    c = synth.uniform_corpus_np(200_000, 20_000, 40, seed=20252)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(256, c.vocab, 8, seed=77)
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=12)
+    for sl, tb in ((0, 0), (12, 0), (16, 1), (14, 100000)):
+        ix.set_opts(supertile_log2=sl, target_blocks=tb)
+        for k in (100, 10):
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"uniform sl={sl} tb={tb} k={k}")
+    ix.close()
+
+
+def test_zipf_dense_and_overflow_paths(rx):
+    """C5-shaped, scaled down: hot terms (df ~ n_docs, negative idf) force the dense-tile path and the overflow
+    packer; ties are abundant."""
+    from sparse_rx import synth
+    c = synth.zipf_corpus_np(120_000, 5_000, 60, seed=20255)
+    df, idf, avgdl = synth.corpus_stats(c)
+    assert idf.min() < 0 and df.max() > 0.9 * c.n_docs
+    q = synth.queries_np(96, c.vocab, 8, seed=5, dist="zipf")
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=14)
+    for sl in (0, 14, 17):
+        ix.set_opts(supertile_log2=sl)
+        for k in (100, 1000, 1):
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf sl={sl} k={k}")
+    ix.close()
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=10)  # small tiles: overflow packer groups several tiles per unit
+    ix.set_opts(supertile_log2=16)
+    _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), "zipf packer")
+    ix.close()
+
+
+def test_splade_dot_f16_k1000(rx):
+    """C4-shaped, scaled down: learned-sparse weights in fp16, 50 terms / query, k = 1000, dot mode."""
+    from sparse_rx import synth
+    c = synth.splade_corpus_np(60_000, 3_000, 100, seed=20254)
+    idf = np.ones(c.vocab, dtype=np.float32)
+    q = synth.queries_np(48, c.vocab, 50, seed=9, dist="zipf", s=0.7, weights="learned")
+    exp = _oracle_batch(c, idf, 1.0, q, 1000, mode=oracle.MODE_TFIDF_F32)
+    for vd in ("f16", "f32"):
+        ix = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", val_dtype=vd, tile_log2=13)
+        _assert_exact(ix.search(*q, 1000), exp, f"splade {vd}")
+        ix.close()
+
+
+def test_edge_cases(rx):
+    from sparse_rx import synth
+    c = synth.zipf_corpus_np(5_000, 700, 30, seed=3)
+    _, idf, avgdl = synth.corpus_stats(c)
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=8)
+    # empty batch
+    d, s, n = ix.search(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), 10)
+    assert d.shape == (0, 10)
+    # empty queries interleaved, a negative-idf-only query, a 1-term query, a > 256-term query (general path)
+    long_terms = np.arange(0, 700, 2, dtype=np.int32)  # 350 distinct terms
+    qs = [np.array([], np.int32), np.array([0], np.int32), np.array([699], np.int32), long_terms, np.array([], np.int32),
+          np.array([0, 1, 2, 3], np.int32)]
+    q_ptr = np.zeros(len(qs) + 1, np.int32)
+    q_ptr[1:] = np.cumsum([len(x) for x in qs])
+    q_term = np.concatenate(qs)
+    q_w = np.ones(len(q_term), np.float32)
+    q_w[::3] = 2.0
+    q = (q_ptr, q_term, q_w)
+    for k in (1, 7, 100, 1024):
+        got = ix.search(*q, k)
+        _assert_exact(got, _oracle_batch(c, idf, avgdl, q, k), f"edge k={k}")
+        assert got[2][0] == 0 and got[2][4] == 0
+    with pytest.raises(ValueError):
+        ix.search(*q, 0)
+    with pytest.raises(ValueError):
+        ix.search(*q, 1025)
+    ix.close()
+    # n_docs not a multiple of the tile, single doc, all-identical docs (one giant tie group)
+    rows = 1000
+    indptr = np.arange(rows + 1, dtype=np.int64) * 2
+    indices = np.tile(np.array([1, 3], np.int32), rows)
+    data = np.ones(2 * rows, np.float32)
+    dl = np.full(rows, 2, np.float32)
+    idf2 = np.array([0.1, 0.7, 0.2, 0.9, 0.3], np.float32)
+    ix = rx.DeviceIndex.from_csr(indptr, indices, data, idf2, doc_lengths=dl, avgdl=2.0, tile_log2=6)
+    qq = (np.array([0, 2], np.int32), np.array([1, 3], np.int32), np.array([1, 1], np.float32))
+    for k in (10, 64, 1000):
+        d, s, n = ix.search(*qq, k)
+        assert n[0] == min(k, rows) and np.array_equal(d[0, : n[0]], np.arange(n[0]))  # ties -> ascending doc id
+        assert len(set(s[0, : n[0]].tolist())) == 1
+    ix.close()
+
+
+def test_merge_topk_matches_single_shard(rx):
+    """Doc-range shards + srx_merge_topk == one index over all docs (the multi-GPU contract, on one device)."""
+    import torch
+    from sparse_rx import synth
+    c = synth.uniform_corpus_np(90_000, 8_000, 30, seed=11)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(64, c.vocab, 6, seed=13)
+    k = 100
+    whole = _dev_index(rx, c, idf, avgdl, tile_log2=12)
+    exp = whole.search(*q, k)
+    whole.close()
+    for shards in (2, 3, 8, 50):
+        bounds = [(c.n_docs * r) // shards for r in range(shards + 1)]
+        parts = []
+        for r in range(shards):
+            a, b = bounds[r], bounds[r + 1]
+            sub_ptr = c.indptr[a: b + 1] - c.indptr[a]
+            lo, hi = c.indptr[a], c.indptr[b]
+            ix = rx.DeviceIndex.from_csr(sub_ptr, c.indices[lo:hi], c.data[lo:hi], idf, doc_lengths=c.doc_lengths[a:b],
+                                         avgdl=avgdl, tile_log2=10, doc_base=a)  # GLOBAL idf / avgdl
+            qd = [torch.as_tensor(x, device="cuda:0") for x in q]
+            parts.append(ix.search_device(*qd, k))
+            torch.cuda.synchronize()
+            ix.close()
+        in_doc = torch.stack([p[0] for p in parts], dim=1)
+        in_score = torch.stack([p[1] for p in parts], dim=1)
+        in_count = torch.stack([p[2] for p in parts], dim=1)
+        d, s, n = rx.merge_topk_device(in_doc, in_score, in_count, k)
+        torch.cuda.synchronize()
+        _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"shards={shards}")
+
+
+def test_impacts_bit_exact(rx):
+    """srx_build_impacts == the reference's fp32 expression (retrieval.py:58,70-71) evaluated by NumPy."""
+    import torch
+    from oracle import np_oracle
+    rng = np.random.default_rng(1)
+    n, nnz = 5000, 200_000
+    tf = rng.integers(1, 40, nnz).astype(np.float32)
+    doc = rng.integers(0, n, nnz).astype(np.int32)
+    dl = rng.integers(1, 3000, n).astype(np.float32)
+    for k1, b, avgdl in ((1.2, 0.75, 137.3), (1.6, 0.8, 55.5), (1000.0, 0.0, 10.0)):
+        exp = np_oracle.impacts_f32(tf, doc, dl, k1, b, avgdl)
+        out = torch.empty(nnz, dtype=torch.float32, device="cuda:0")
+        t = [torch.as_tensor(x, device="cuda:0") for x in (tf, doc, dl)]
+        rc = rx._capi.lib().srx_build_impacts(0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), nnz, k1, b, avgdl,
+                                              out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+def test_larger_properties(rx):
+    """1 M docs (C2 shape): exact vs the oracle on a query sample + size-independent properties on the batch:
+    descending order, doc-unique, scores of returned docs recomputed exactly from the CSR rows, idempotence,
+    and shard-invariance (k-prefix property: top-10 is the prefix of top-100)."""
+    from sparse_rx import synth
+    c = synth.uniform_corpus_np(1_000_000, 50_000, 50, seed=20252)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(1000, c.vocab, 8, seed=20252 + 1)
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=14)
+    d100, s100, n100 = ix.search(*q, 100)
+    d10, s10, n10 = ix.search(*q, 10)
+    assert np.array_equal(d10, d100[:, :10]) and np.array_equal(s10, s100[:, :10])
+    again = ix.search(*q, 100)
+    assert all(np.array_equal(a, b) for a, b in zip(again, (d100, s100, n100)))
+    for qi in range(0, 1000, 50):
+        c_ = n100[qi]
+        assert_canonical_order(d100[qi, :c_], s100[qi, :c_])
+    sample = slice(0, 24)
+    qs = (q[0][: 25] - q[0][0], q[1][q[0][0]: q[0][24]], q[2][q[0][0]: q[0][24]])
+    exp = _oracle_batch(c, idf, avgdl, qs, 100)
+    _assert_exact((d100[sample], s100[sample], n100[sample]), exp, "1M sample")
+    ix.close()
