@@ -87,9 +87,9 @@ typedef struct srx_index srx_index;
 /* Search-time tuning knobs; zero-initialise for defaults. */
 typedef struct {
     int32_t supertile_log2; /* docs per hash-accumulated unit = 2^supertile_log2 (>= tile_log2); 0 = auto */
-    int32_t target_blocks;  /* workgroups to aim for when splitting a query's doc range; 0 = auto (2048) */
+    int32_t target_blocks;  /* workgroups to aim for when splitting a query's doc range; 0 = auto (8192) */
     int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
-    int32_t reserved;
+    int32_t reserved;       /* debug bits: 8 = route every query through the tier-2 (block) kernel */
 } srx_search_opts;
 
 int srx_version(void);
@@ -142,11 +142,11 @@ int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *
                         int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
-/* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = score
- * kernel, h_ms[1] = merge kernel, h_ms[2] = whole call (milliseconds, hipEventElapsedTime between events
- * recorded on the search stream around each kernel).  Synchronises the events, resets the window and returns
- * the number of calls averaged (or a negative srx_status). */
-int srx_profile_read(srx_index *ix, float *h_ms3);
+/* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = tier-1
+ * wave kernel, h_ms[1] = tier-2 block kernel, h_ms[2] = merge kernel, h_ms[3] = whole call (milliseconds,
+ * hipEventElapsedTime between events recorded on the search stream around each kernel).  Synchronises the
+ * events, resets the window and returns the number of calls averaged (or a negative srx_status). */
+int srx_profile_read(srx_index *ix, float *h_ms4);
 
 #ifdef __cplusplus
 }

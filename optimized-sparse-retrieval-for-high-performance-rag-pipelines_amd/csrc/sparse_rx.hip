@@ -5,14 +5,19 @@
 //   simd_tfidf_score     rag_system/pipeline/evaluate_rag_pipeline.py:95-121
 //   fast_topk_selection  rag_system/core/retrieval.py:79-92      (+ score>0 filter :292-296)
 //
-// Design: the index is term-major (CSC) with a tile skip table.  One 256-thread
-// workgroup walks one (query, doc-range split); the split is cut into *units* of docs.  A unit's
-// postings are streamed from HBM with coalesced loads (terms ascending) and accumulated per doc in LDS:
-//   sparse unit  (<= HASH_CAP postings)  -> open-addressing hash table in LDS  (doc -> fp32 sum)
-//   dense tile   (more than that in G docs) -> dense fp32 accumulators acc[G] in LDS
-// Contributions of one doc are added in ascending term id (barrier between terms), so sums are
-// bit-identical to the reference's CSR row order.  After each unit an exact radix select keeps the
-// running top-k (score desc, doc asc) in LDS.  A second kernel merges the per-split lists and sorts.
+// Design: the index is term-major (CSC) with a tile skip table.  A query's doc range is cut
+// into *units* (supertiles of 2^s docs).  Two tiers score them, a merge kernel ranks:
+//   tier 1  srx_wave_kernel   ONE WAVEFRONT per (query, split): streams each term's run of the unit from HBM
+//           (coalesced, terms ascending, 64 postings per step), resolves doc -> slot in a wave-private LDS hash
+//           table with ds_cmpst, then adds contributions with ds_add_f32 in step order.  LDS executes one
+//           wave's instructions in order, so per-doc sums are accumulated in ascending term id without any
+//           barrier -- bit-identical to the reference's CSR row order.  A lazy top-k list lives in LDS; an
+//           exact wave-level radix select shrinks it when it fills.  Units with too many postings (hot
+//           terms), queries with > 64 terms and k > 128 are flagged for tier 2.
+//   tier 2  srx_score_kernel  one 256-thread workgroup per (query, split): block-level hash units of up to 4096
+//           postings, a greedy tile packer, and dense fp32 accumulators acc[G] in LDS for tiles whose postings
+//           exceed that (barrier between terms keeps the summation order).  Handles everything.
+//   merge   srx_merge_kernel  exact top-k over the per-split lists + bitonic rank by (score desc, doc asc).
 // No MFMA (sparse gather/reduce, HBM-bound), no global float atomics (order must be deterministic).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no fused multiply-add: the reference's
@@ -49,6 +54,16 @@ constexpr int RADIX_BINS = 1 << RADIX_BITS;  // 2048-bin histogram (aliases the 
 constexpr int MAX_TPS = 64;                 // tiles per supertile handled by the overflow packer
 constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thread (4096 per workgroup)
 constexpr int EMPTY_KEY = -1;
+// tier 1 (one wavefront per (query, split))
+constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
+constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
+constexpr int W_R = 16;                     // postings per lane per unit held in registers (steps)
+constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
+constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
+constexpr int W_MCAP = 64;                  // ... at most this many such postings per unit (one per lane)
+constexpr int W_LCAP = 256;                 // lazy top-k list capacity (>= W_KMAX + 64)
+constexpr int W_KMAX = 128;                 // largest k served by tier 1
+constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
 
 thread_local char g_err[512] = "";
 
@@ -244,7 +259,9 @@ struct TopkShared {
 
 // Fold the candidates of one unit (register arrays ubits/udoc, ubits == 0 -> none) into the list.
 // Candidates must already satisfy ubits >= tau.  hist = RADIX_BINS words of free LDS.
-template <int N>
+// LAZY: candidates are appended while the list has room (capacity KMAX) and the selection only runs when it
+// would overflow; the caller finishes with topk_shrink().  !LAZY: the list never exceeds k.
+template <int N, bool LAZY>
 __device__ void topk_fold(unsigned (&ubits)[N], const int (&udoc)[N], int k, TopkShared &tk, unsigned *hist) {
     const int tid = threadIdx.x;
     const unsigned n_old = tk.count;  // read BEFORE the barriers below: later appends must not be seen by slow threads
@@ -252,8 +269,8 @@ __device__ void topk_fold(unsigned (&ubits)[N], const int (&udoc)[N], int k, Top
 #pragma unroll
     for (int n = 0; n < N; ++n) mine += (ubits[n] != 0);
     const unsigned n_new = block_sum(mine, tk.red);
-    if (n_new == 0) return;
-    if (n_old + n_new <= (unsigned)k) {
+    if (n_new == 0 && n_old <= (unsigned)k) return;
+    if (n_old + n_new <= (unsigned)(LAZY ? KMAX : k)) {
 #pragma unroll
         for (int n = 0; n < N; ++n)
             if (ubits[n] != 0) {
@@ -324,6 +341,15 @@ __device__ void topk_fold(unsigned (&ubits)[N], const int (&udoc)[N], int k, Top
     __syncthreads();
 }
 
+// Shrink a lazily grown list to its top k (no-op when it already fits).
+__device__ void topk_shrink(int k, TopkShared &tk, unsigned *hist) {
+    if (tk.count <= (unsigned)k) return;  // uniform: count was last written before a barrier
+    unsigned none_b[1] = {0u};
+    const int none_d[1] = {0};
+    __syncthreads();
+    topk_fold<1, false>(none_b, none_d, k, tk, hist);
+}
+
 __device__ __forceinline__ float load_val(const float *p, int64_t i) { return p[i]; }
 __device__ __forceinline__ float load_val(const __half *p, int64_t i) { return __half2float(p[i]); }
 
@@ -347,7 +373,7 @@ struct ScoreShared {
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
 // scores into the running top-k.  nt = terms in this pass.
 template <typename VT>
-__device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k) {
+__device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k, int dbg = 0) {
     const int tid = threadIdx.x;
     int *keys = reinterpret_cast<int *>(S.tbl);
     float *vals = reinterpret_cast<float *>(S.tbl + SLOTS);
@@ -388,7 +414,7 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
             if (s < n_steps) {
                 const int i = S.st_term[s];
                 if (s > 0 && S.st_term[s - 1] != i) __syncthreads();  // next term: order adds per doc
-                if (d[r] >= 0) {
+                if (d[r] >= 0 && !(dbg & 2)) {
                     const float c = (v[r] * S.m_idf[i]) * S.m_qw[i];
                     unsigned h = ((unsigned)d[r] * 0x9E3779B1u) >> (32 - 13);
                     for (;;) {
@@ -429,7 +455,7 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
         }
     }
     __syncthreads();  // table is free from here: vals region doubles as the radix histogram
-    topk_fold<NPT_HASH>(ubits, udoc, k, S.tk, S.tbl + SLOTS);
+    if (!(dbg & 1)) topk_fold<NPT_HASH, true>(ubits, udoc, k, S.tk, S.tbl + SLOTS);
 }
 
 // Dense-accumulate one tile of G docs [tile_base, tile_base + G) described by m_start/m_len.
@@ -492,15 +518,16 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
         udoc[n] = tile_base + o;
     }
     __syncthreads();  // accumulators are in registers; their LDS doubles as the radix histogram
-    topk_fold<NPT_DENSE>(ubits, udoc, k, S.tk, S.tbl);
+    topk_fold<NPT_DENSE, true>(ubits, udoc, k, S.tk, S.tbl);
 }
 
 template <typename VT>
 __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                                const int32_t *__restrict__ q_term,
                                                                const float *__restrict__ q_weight, int nq, int k,
-                                                               int n_splits, int super_log2, int n_super,
-                                                               int32_t *__restrict__ cand_doc,
+                                                               int n_splits, int super_log2, int n_super, int dbg,
+                                                               const unsigned *__restrict__ ovf, int ovf_words,
+                                                               int lists_per_q, int32_t *__restrict__ cand_doc,
                                                                float *__restrict__ cand_score,
                                                                int32_t *__restrict__ cand_count) {
     __shared__ ScoreShared S;
@@ -508,11 +535,22 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
     const int q = blockIdx.x / n_splits;
     const int split = blockIdx.x - q * n_splits;
     if (q >= nq) return;
+    const int64_t list = (int64_t)q * lists_per_q + n_splits + split;  // tier-2 lists follow the tier-1 lists
     const int t0 = q_ptr[q];
     const int nt_all = q_ptr[q + 1] - t0;
     // this split's supertiles [su_lo, su_hi)
     const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
+    // Tier 2 takes the whole query when tier 1 cannot serve it, otherwise only the units tier 1 flagged.
+    const bool all_units = (nt_all > W_MAXT) || (k > W_KMAX) || (super_log2 > W_UNIT_LOG2) || (dbg & 8);
+    const unsigned *my_ovf = ovf + (int64_t)q * ovf_words;
+    bool any = all_units && nt_all > 0;
+    if (!all_units && nt_all > 0)
+        for (int wd = su_lo >> 5; wd <= (su_hi - 1) >> 5 && su_lo < su_hi; ++wd) any = any || (my_ovf[wd] != 0u);
+    if (!any) {  // uniform
+        if (tid == 0) cand_count[list] = 0;
+        return;
+    }
     const int tps_log2 = super_log2 - ix.tile_log2;  // tiles per supertile (log2)
     const int tps = 1 << tps_log2;
     const int row = ix.n_tiles + 1;
@@ -527,27 +565,26 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
 
     const int n_pass = (nt_all + MAXT - 1) / MAXT;  // 1 unless the query has > 256 distinct terms
 
-    if (n_pass == 1 && nt_all > 0) {
-        // ---- fast path: thread i owns term i; unit boundaries are prefetched one unit ahead ----
+    if (n_pass == 1) {
+        // ---- thread i owns term i ----
         const int nt = nt_all;
-        int term = 0;
         int64_t base = 0;
         const int32_t *skip_row = ix.tile_skip;
         if (tid < nt) {
-            term = q_term[t0 + tid];
+            const int term = q_term[t0 + tid];
             base = ix.term_ptr[term];
             skip_row = ix.tile_skip + (int64_t)term * row;
             S.m_idf[tid] = ix.idf[term];
             S.m_qw[tid] = q_weight[t0 + tid];
         }
-        int lo = 0, hi = 0, hi_next = 0;
-        if (tid < nt && su_lo < su_hi) {
-            lo = skip_row[min(su_lo << tps_log2, ix.n_tiles)];
-            hi = skip_row[min((su_lo + 1) << tps_log2, ix.n_tiles)];
-        }
         for (int su = su_lo; su < su_hi; ++su) {
-            if (tid < nt && su + 1 < su_hi) hi_next = skip_row[min((su + 2) << tps_log2, ix.n_tiles)];
-            const int my_len = (tid < nt) ? hi - lo : 0;
+            if (!all_units && !((my_ovf[su >> 5] >> (su & 31)) & 1u)) continue;  // uniform
+            int lo = 0, hi = 0;
+            if (tid < nt) {
+                lo = skip_row[min(su << tps_log2, ix.n_tiles)];
+                hi = skip_row[min((su + 1) << tps_log2, ix.n_tiles)];
+            }
+            const int my_len = hi - lo;
             const unsigned P = block_sum((unsigned)my_len, S.tk.red);
             if (P > 0 && P <= (unsigned)HASH_CAP) {
                 if (tid < nt) {
@@ -555,7 +592,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
                     S.m_len[tid] = my_len;
                 }
                 __syncthreads();
-                hash_unit<VT>(S, ix, nt, my_len, k);
+                hash_unit<VT>(S, ix, nt, my_len, k, dbg);
             } else if (P > 0) {
                 // ---- overflow: pack this supertile's tiles greedily into units of <= HASH_CAP postings;
                 //      a single tile above that is accumulated densely ----
@@ -605,7 +642,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
                     }
                     __syncthreads();
                     if (GP <= (unsigned)HASH_CAP) {
-                        hash_unit<VT>(S, ix, nt, glen, k);
+                        hash_unit<VT>(S, ix, nt, glen, k, dbg);
                     } else {  // one dense tile (gb == ga + 1 by construction)
                         const int tile_base = ga << ix.tile_log2;
                         dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
@@ -615,10 +652,8 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
                     }
                 }
             }
-            lo = hi;
-            hi = hi_next;
         }
-    } else if (nt_all > 0) {
+    } else {
         // ---- general path (> MAXT query terms): tile by tile, dense accumulators, term passes in
         //      ascending order so the per-doc summation order is unchanged ----
         const int ja = su_lo << tps_log2;
@@ -646,13 +681,417 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
 
     // ---- emit this split's list (unordered; the merge kernel ranks) ----
     __syncthreads();
+    topk_shrink(k, S.tk, S.tbl);
     const unsigned cnt = S.tk.count;
-    const int64_t o = (int64_t)blockIdx.x * k;
+    const int64_t o = list * k;
     for (unsigned i = tid; i < cnt; i += THREADS) {
         cand_doc[o + i] = S.tk.doc[i];
         cand_score[o + i] = __uint_as_float(S.tk.bits[i]);
     }
-    if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
+    if (tid == 0) cand_count[list] = (int)cnt;
+}
+
+// ================================================================================================
+// Tier 1: one wavefront per (query, split).  Wave-synchronous: no s_barrier anywhere; LDS executes one
+// wave's DS instructions in order, wsync() only stops the compiler from reordering across the hand-off.
+// ================================================================================================
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct WaveShared {
+    unsigned bm[W_BM_WORDS + 64];  // doc bitmap of the current unit (1 bit per doc) + one dummy word per lane
+    int mkeys[W_MSLOTS];           // small hash table for docs matched by more than one query term
+    float mvals[W_MSLOTS];
+    unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
+    int ldoc[W_LCAP];
+    int ml_d[W_MCAP];              // postings of multi-term docs of the current unit (doc, contribution, term slot)
+    float ml_c[W_MCAP];
+    int ml_t[W_MCAP];
+};
+
+// Exact k-th largest of the wave's keys (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix, 256-bin LDS
+// histogram, 4 bins per lane.  Requires 1 <= k <= #candidates.
+template <int N>
+__device__ unsigned wave_radix_kth(const unsigned (&key)[N], unsigned k, unsigned mx, unsigned mn, unsigned n_cand,
+                                   unsigned *hist, unsigned *n_gt, unsigned *n_eq) {
+    if (mx == mn) {
+        *n_gt = 0;
+        *n_eq = n_cand;
+        return mx;
+    }
+    const int lane = threadIdx.x;
+    const int hb = 31 - __clz(mx ^ mn);
+    unsigned prefix = mx & ~((2u << hb) - 1u);
+    int shift = hb + 1;
+    unsigned krem = k, gt = 0, eq = 0;
+    while (shift > 0) {
+        const int w = shift < 8 ? shift : 8;
+        shift -= w;
+        const int hi_shift = shift + w;
+        reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        wsync();
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const unsigned x = key[n];
+            if (x != 0 && ((x ^ prefix) >> hi_shift) == 0) atomicAdd(&hist[(x >> shift) & ((1u << w) - 1u)], 1u);
+        }
+        wsync();
+        const uint4 a = reinterpret_cast<const uint4 *>(hist)[lane];
+        const unsigned h[4] = {a.x, a.y, a.z, a.w};
+        const unsigned s = (a.x + a.y) + (a.z + a.w);
+        unsigned suf = s;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_down(suf, o);
+            if (lane + o < 64) suf += v;
+        }
+        const unsigned above = suf - s;
+        const bool own = above < krem && krem <= suf;
+        unsigned d = 0, ab = 0, cn = 0;
+        if (own) {
+            unsigned run = above;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                if (run + h[i] >= krem) {
+                    d = (unsigned)(4 * lane + i);
+                    ab = run;
+                    cn = h[i];
+                    break;
+                }
+                run += h[i];
+            }
+        }
+        const int owner = __ffsll((unsigned long long)__ballot(own)) - 1;
+        d = (unsigned)__shfl((int)d, owner);
+        ab = (unsigned)__shfl((int)ab, owner);
+        eq = (unsigned)__shfl((int)cn, owner);
+        krem -= ab;
+        gt += ab;
+        prefix |= d << shift;
+        wsync();
+    }
+    *n_gt = gt;
+    *n_eq = eq;
+    return prefix;
+}
+
+// Shrink the wave's list (count > k entries in LDS) to its exact top k; returns tau = key of the k-th.
+__device__ __noinline__ unsigned wave_list_select(WaveShared &S, unsigned count, int k) {
+    constexpr int LPT = W_LCAP / 64;  // list entries per lane
+    const int lane = threadIdx.x;
+    unsigned key[LPT];
+    int doc[LPT];
+    unsigned mx = 0, mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const unsigned i = lane + 64 * j;
+        const bool ok = i < count;
+        key[j] = ok ? S.lbits[i] : 0u;
+        doc[j] = ok ? S.ldoc[i] : 0;
+        if (ok) {
+            mx = max(mx, key[j]);
+            mn = min(mn, key[j]);
+        }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    wsync();  // the list is in registers now: its LDS (lbits) serves as the histogram
+    unsigned n_gt, n_eq;
+    const unsigned T = wave_radix_kth<LPT>(key, (unsigned)k, mx, mn, count, S.lbits, &n_gt, &n_eq);
+    const unsigned need = (unsigned)k - n_gt;
+    unsigned T2 = 0;
+    if (n_eq > need) {  // uniform
+        unsigned key2[LPT];
+        unsigned mx2 = 0, mn2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            key2[j] = (key[j] == T) ? (0x7FFFFFFFu - (unsigned)doc[j]) : 0u;
+            if (key2[j] != 0) {
+                mx2 = max(mx2, key2[j]);
+                mn2 = min(mn2, key2[j]);
+            }
+        }
+        mx2 = wave_max(mx2);
+        mn2 = wave_min(mn2);
+        unsigned g2, e2;
+        T2 = wave_radix_kth<LPT>(key2, need, mx2, mn2, n_eq, S.lbits, &g2, &e2);
+    }
+    wsync();
+    unsigned base = 0;  // deterministic compaction (ballot prefix), wave-uniform running count
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const unsigned x = key[j];
+        const bool take = x != 0 && ((x > T) || (x == T && (0x7FFFFFFFu - (unsigned)doc[j]) >= T2));
+        const unsigned long long m = __ballot(take);
+        if (take) {
+            const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            S.lbits[p] = x;
+            S.ldoc[p] = doc[j];
+        }
+        base += (unsigned)__popcll(m);
+    }
+    wsync();
+    return T;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
+                                                      const int32_t *__restrict__ q_term,
+                                                      const float *__restrict__ q_weight, int nq, int k, int n_splits,
+                                                      int super_log2, int n_super, int dbg,
+                                                      unsigned *__restrict__ ovf, int ovf_words, int lists_per_q,
+                                                      int32_t *__restrict__ cand_doc, float *__restrict__ cand_score,
+                                                      int32_t *__restrict__ cand_count) {
+    __shared__ WaveShared S;
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x / n_splits;
+    const int split = blockIdx.x - q * n_splits;
+    if (q >= nq) return;
+    const int64_t list = (int64_t)q * lists_per_q + split;
+    const int t0 = q_ptr[q];
+    const int nt = q_ptr[q + 1] - t0;
+    if (nt == 0 || nt > W_MAXT || k > W_KMAX || super_log2 > W_UNIT_LOG2 || (dbg & 8)) {  // tier 2 serves it
+        if (lane == 0) cand_count[list] = 0;
+        return;
+    }
+    const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
+    const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
+    const int tps_log2 = super_log2 - ix.tile_log2;
+    const int row = ix.n_tiles + 1;
+    const int32_t *post_doc = ix.post_doc;
+    const VT *post_val = reinterpret_cast<const VT *>(ix.post_val);
+
+    for (int i = lane; i < (W_BM_WORDS + 64) / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
+    // Query term t owns a group of lpt = 64 / 2^ceil(log2 nt) lanes; lane j of the group handles postings
+    // j, j + lpt, j + 2 lpt, ... of the term's run inside the unit.  Term data stays in registers.
+    int lg = 0;
+    while ((1 << lg) < nt) ++lg;
+    const int lpt_log2 = 6 - lg;
+    const int lpt = 1 << lpt_log2;
+    const int tslot = lane >> lpt_log2;  // my term slot (ascending term id)
+    const int jl = lane & (lpt - 1);
+    const bool has_term = tslot < nt;
+    int64_t base = 0;
+    const int32_t *skip_row = ix.tile_skip;
+    float my_idf = 0.f, my_qw = 0.f;
+    if (has_term) {
+        const int term = q_term[t0 + tslot];
+        base = ix.term_ptr[term];
+        skip_row = ix.tile_skip + (int64_t)term * row;
+        my_idf = ix.idf[term];
+        my_qw = q_weight[t0 + tslot];
+    }
+    wsync();
+    unsigned count = 0, tau = 0;  // wave-uniform
+
+    // unit boundary j of my term: #postings with doc < (j << super_log2)
+    auto bound = [&](int j) __attribute__((always_inline)) -> int {
+        return has_term ? skip_row[min(j << tps_log2, ix.n_tiles)] : 0;
+    };
+
+    // Issue the loads of my term's run [lo, lo + len) of the unit: step r <-> posting jl + r * lpt.  Always exactly
+    // 2 * W_R loads, no branches (idle lanes / steps read posting 0), so that the compiler can wait for THIS unit's
+    // data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.  Returns the number of
+    // steps the unit needs (> W_R: does not fit the registers -> nothing useful is loaded, tier 2 takes the unit).
+    auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
+        const int n_steps = (uni((int)wave_max((unsigned)len)) + lpt - 1) >> lpt_log2;
+        const int len_eff = (n_steps <= W_R) ? len : 0;
+        const int64_t g0 = base + lo + jl;
+#pragma unroll
+        for (int r = 0; r < W_R; ++r) {
+            const int p = jl + (r << lpt_log2);
+            const int64_t g = (p < len_eff) ? g0 + (r << lpt_log2) : 0;
+            d[r] = post_doc[g];
+            v[r] = load_val(post_val, g);
+        }
+        return n_steps;
+    };
+
+    auto append = [&](bool cand, unsigned bits, int doc) __attribute__((always_inline)) {
+        const unsigned long long m = __ballot(cand);
+        if (m != 0ull) {  // uniform
+            if (count > (unsigned)(W_LCAP - 64)) {  // make room for up to 64 more entries
+                tau = wave_list_select(S, count, k);
+                count = (unsigned)k;
+            }
+            const bool c2 = cand && bits >= tau;  // tau may just have risen
+            const unsigned long long m2 = __ballot(c2);
+            if (c2) {
+                const unsigned p = count + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
+                S.lbits[p] = bits;
+                S.ldoc[p] = doc;
+            }
+            count += (unsigned)__popcll(m2);
+        }
+    };
+
+    // Score one unit from registers.  Pass 1 sets every posting's doc bit (ds_or_rtn): a bit found already set means
+    // another posting of the same doc came earlier.  Pass 2: those lanes clear the bit again, which tells the earlier
+    // posting's lane too.  Pass 3: bit still set = the doc is matched by exactly one term -> its score is the single
+    // contribution 0 + c, straight from registers.  Docs matched by several terms (rare) are collected in a small
+    // LDS list and summed in a hash table in rounds of ascending term id; one wave's DS instructions execute in
+    // order, so the sum is accumulated exactly like the reference's CSR row walk.  false -> the unit goes to tier 2.
+    auto process = [&](int su, int len, int n_steps, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+        const int ubase = su << super_log2;
+        unsigned old[W_R];
+        unsigned valid = 0;
+#pragma unroll
+        for (int r = 0; r < W_R; ++r) {
+            if (r < n_steps) {  // uniform
+                const bool ok = jl + (r << lpt_log2) < len;
+                if (ok) valid |= 1u << r;
+                const unsigned off = (unsigned)(d[r] - ubase);
+                const unsigned w = ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane);
+                old[r] = atomicOr(&S.bm[w], ok ? (1u << (off & 31)) : 0u);
+            }
+        }
+        unsigned dup = 0;
+#pragma unroll
+        for (int r = 0; r < W_R; ++r) {
+            if (r < n_steps) {
+                const unsigned off = (unsigned)(d[r] - ubase);
+                if (((valid >> r) & 1u) && ((old[r] >> (off & 31)) & 1u)) dup |= 1u << r;
+            }
+        }
+        const bool any_dup = __ballot(dup != 0) != 0ull;  // uniform
+        unsigned multi = 0;
+        if (any_dup) {
+#pragma unroll
+            for (int r = 0; r < W_R; ++r) {
+                const unsigned off = (unsigned)(d[r] - ubase);
+                if ((dup >> r) & 1u) atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+            }
+#pragma unroll
+            for (int r = 0; r < W_R; ++r) {
+                if (r < n_steps) {
+                    const bool ok = (valid >> r) & 1u;
+                    const unsigned off = (unsigned)(d[r] - ubase);
+                    const unsigned x = S.bm[ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)];
+                    if (ok && !((x >> (off & 31)) & 1u)) multi |= 1u << r;
+                }
+            }
+        }
+        // restore the bitmap (every touched word back to 0)
+#pragma unroll
+        for (int r = 0; r < W_R; ++r) {
+            if (r < n_steps) {
+                const unsigned off = (unsigned)(d[r] - ubase);
+                S.bm[((valid >> r) & 1u) ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)] = 0u;
+            }
+        }
+        const unsigned n_multi = any_dup ? uniu(wave_sum((unsigned)__popc(multi))) : 0u;
+        if (n_multi > (unsigned)W_MCAP) return false;
+        if (dbg & 2) return true;
+
+        unsigned mcnt = 0;  // uniform: entries in the multi list
+#pragma unroll
+        for (int r = 0; r < W_R; ++r) {
+            if (r < n_steps) {
+                const float c = 0.0f + (v[r] * my_idf) * my_qw;
+                const unsigned b = __float_as_uint(c);
+                const bool ok = (valid >> r) & 1u;
+                const bool mu = (multi >> r) & 1u;
+                if (!(dbg & 1)) append(ok && !mu && c > 0.0f && b >= tau, b, d[r]);  // docs matched by a single term
+                if (n_multi > 0) {  // uniform
+                    const unsigned long long mm = __ballot(mu);
+                    if (mm != 0ull) {
+                        if (mu) {
+                            const unsigned p = mcnt + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+                            S.ml_d[p] = d[r];
+                            S.ml_c[p] = c;
+                            S.ml_t[p] = tslot;
+                        }
+                        mcnt += (unsigned)__popcll(mm);
+                    }
+                }
+            }
+        }
+        if (n_multi > 0) {
+            wsync();
+            const bool mine = (unsigned)lane < mcnt;  // W_MCAP == 64: one list entry per lane
+            const int md = mine ? S.ml_d[lane] : 0;
+            const float mc = mine ? S.ml_c[lane] : 0.f;
+            const int mt = mine ? S.ml_t[lane] : 0x7FFFFFFF;
+            bool pending = mine, claimed = false;
+            unsigned h = ((unsigned)md * 0x9E3779B1u) >> (32 - 8);
+            while (__ballot(pending) != 0ull) {  // one round per distinct term, ascending
+                const int tcur = uni((int)wave_min(pending ? (unsigned)mt : 0x7FFFFFFFu));
+                if (pending && mt == tcur) {  // docs are unique inside one term
+                    for (;;) {
+                        const int o = atomicCAS(&S.mkeys[h], EMPTY_KEY, md);
+                        if (o == EMPTY_KEY) {
+                            S.mvals[h] = mc;  // first term of this doc
+                            claimed = true;
+                            break;
+                        }
+                        if (o == md) {
+                            S.mvals[h] = S.mvals[h] + mc;  // a later term: in-order read-add-store
+                            break;
+                        }
+                        h = (h + 1) & (W_MSLOTS - 1);
+                    }
+                    pending = false;
+                }
+                wsync();
+            }
+            if (!(dbg & 1)) {
+                const float sc = claimed ? S.mvals[h] : 0.f;
+                const unsigned b = __float_as_uint(sc);
+                append(claimed && sc > 0.0f && b >= tau, b, md);
+            }
+            wsync();
+            reinterpret_cast<int4 *>(S.mkeys)[lane] = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+            wsync();
+        }
+        return true;
+    };
+
+    auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
+        if (lane == 0) atomicOr(&ovf[(int64_t)q * ovf_words + (su >> 5)], 1u << (su & 31));
+    };
+
+    // ---- software pipeline over units, unrolled by two (register sets A / B alternate): issue the loads of unit
+    //      u+1, then score unit u from registers ----
+    int dA[W_R], dB[W_R];
+    float vA[W_R], vB[W_R];
+    int b0 = bound(su_lo), b1 = bound(su_lo + 1), b2 = bound(su_lo + 2);  // b_j = boundary j; unit u = [b_u, b_{u+1})
+    int lenA = b1 - b0, lenB = 0, nA = 0, nB = 0;
+    if (su_lo >= su_hi) lenA = 0;
+    nA = issue(b0, lenA, dA, vA);
+    // one stage: unit su is in (lenc, nc, d, v); unit su+1 goes to (lenn, nn, dn, vn)
+    auto stage = [&](int su, int lenc, int nc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int &nn,
+                     int (&dn)[W_R], float (&vn)[W_R]) __attribute__((always_inline)) {
+        const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
+        lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
+        nn = issue(b1, lenn, dn, vn);
+        if (nc > W_R) {
+            flag_tier2(su);
+        } else if (nc > 0) {
+            if (!process(su, lenc, nc, d, v)) flag_tier2(su);
+        }
+        b1 = b2;
+        b2 = b3;
+    };
+    for (int su = su_lo; su < su_hi; su += 2) {
+        stage(su, lenA, nA, dA, vA, lenB, nB, dB, vB);
+        if (su + 1 < su_hi) stage(su + 1, lenB, nB, dB, vB, lenA, nA, dA, vA);
+    }
+    if (count > (unsigned)k) {
+        tau = wave_list_select(S, count, k);
+        count = (unsigned)k;
+    }
+    const int64_t o = list * k;
+    for (unsigned i = lane; i < count; i += 64) {
+        cand_doc[o + i] = S.ldoc[i];
+        cand_score[o + i] = __uint_as_float(S.lbits[i]);
+    }
+    if (lane == 0) cand_count[list] = (int)count;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -710,7 +1149,7 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
             }
         }
     }
-    topk_fold<MERGE_NPT>(ubits, udoc, k, M.tk, M.hist);
+    topk_fold<MERGE_NPT, false>(ubits, udoc, k, M.tk, M.hist);
     const unsigned cnt = M.tk.count;
     if (!final_pass) {
         const int64_t o = ((int64_t)q * n_groups + g) * k;
@@ -795,10 +1234,11 @@ __global__ void srx_tile_skip_kernel(const int64_t *__restrict__ term_ptr, const
 // C ABI
 // ================================================================================================
 constexpr int PROF_SLOTS = 256;
+constexpr int PROF_EVENTS = 4;  // start, after tier 1, after tier 2, after merge
 struct srx_index {
     srx_index_desc d;
     srx_search_opts opts;
-    hipEvent_t *ev;   // PROF_SLOTS x 3 events (start, after score kernel, after merge kernel), created lazily
+    hipEvent_t *ev;   // PROF_SLOTS x PROF_EVENTS events, created lazily
     int ev_n;         // profiled calls recorded since the last srx_profile_read (<= PROF_SLOTS, then it wraps)
     int64_t ev_calls;
 };
@@ -852,7 +1292,7 @@ SRX_API int srx_index_create(const srx_index_desc *d, srx_index **out) {
 SRX_API void srx_index_destroy(srx_index *ix) {
     if (!ix) return;
     if (ix->ev) {
-        for (int i = 0; i < 3 * PROF_SLOTS; ++i) (void)hipEventDestroy(ix->ev[i]);
+        for (int i = 0; i < PROF_EVENTS * PROF_SLOTS; ++i) (void)hipEventDestroy(ix->ev[i]);
         delete[] ix->ev;
     }
     delete ix;
@@ -869,11 +1309,11 @@ SRX_API int srx_index_set_opts(srx_index *ix, const srx_search_opts *o) {
 
 namespace {
 struct Plan {
-    int super_log2, n_super, n_splits;
+    int super_log2, n_super, n_splits, ovf_words, lists_per_q;
 };
 
-// Supertile = the doc range one hash unit covers.  Auto rule: the largest power of two (tile .. tile*64)
-// for which an 8-term query of average terms is expected to stay under ~60 % of HASH_CAP.
+// Supertile (unit) = the doc range one tier-1 hash unit covers.  Auto rule: the largest power of two
+// (tile .. tile*64) for which an 8-term query of average terms is expected to stay under ~55 % of W_CAP.
 Plan make_plan(const srx_index *ix, int nq, int k) {
     Plan p;
     const srx_index_desc &d = ix->d;
@@ -881,18 +1321,20 @@ Plan make_plan(const srx_index *ix, int nq, int k) {
     if (sl == 0) {
         const double per_doc_per_term = (double)d.nnz / ((double)d.n_docs * (double)d.vocab);  // E[postings of a term per doc]
         sl = d.tile_log2;
-        while (sl < d.tile_log2 + 6 && 8.0 * per_doc_per_term * (double)(2ll << sl) <= 0.6 * HASH_CAP) ++sl;
+        while (sl < d.tile_log2 + 6 && sl < W_UNIT_LOG2 && 8.0 * per_doc_per_term * (double)(2ll << sl) <= 0.6 * W_CAP) ++sl;
     }
     p.super_log2 = sl;
     p.n_super = (int)((d.n_docs + (1ll << sl) - 1) >> sl);
-    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 2048;
+    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 8192;  // wave-sized workgroups
     int ns = target / (nq > 0 ? nq : 1);
     if (ns < 1) ns = 1;
     if (ns > p.n_super) ns = p.n_super;
-    const int cap = (MERGE_NPT * THREADS) / (k > 0 ? k : 1);  // merge kernel takes <= 4096 candidates per group
+    const int cap = (MERGE_NPT * THREADS) / (2 * (k > 0 ? k : 1));  // merge takes <= 4096 candidates: 2 tiers x splits x k
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     p.n_splits = ns;
+    p.ovf_words = (p.n_super + 31) / 32;
+    p.lists_per_q = 2 * ns;  // [0, ns): tier 1, [ns, 2 ns): tier 2
     return p;
 }
 }  // namespace
@@ -900,8 +1342,8 @@ Plan make_plan(const srx_index *ix, int nq, int k) {
 SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int32_t k) {
     if (!ix || nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search_workspace_bytes: bad argument%s");
     const Plan p = make_plan(ix, nq, k);
-    const int64_t lists = (int64_t)nq * p.n_splits;
-    return lists * k * 8 + lists * 4 + 256;
+    const int64_t lists = (int64_t)nq * p.lists_per_q;
+    return lists * k * 8 + lists * 4 + (int64_t)nq * p.ovf_words * 4 + 256;
 }
 
 SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
@@ -916,11 +1358,13 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ix->d.device));
     const Plan p = make_plan(ix, nq, k);
-    const int64_t lists = (int64_t)nq * p.n_splits;
+    const int64_t lists = (int64_t)nq * p.lists_per_q;
+    const int64_t blocks = (int64_t)nq * p.n_splits;
     if (lists > 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_search: nq * splits overflows the grid%s");
     int32_t *cand_doc = (int32_t *)workspace;
     float *cand_score = (float *)(cand_doc + lists * k);
     int32_t *cand_count = (int32_t *)(cand_score + lists * k);
+    unsigned *ovf = (unsigned *)(cand_count + lists);
 
     IndexView v;
     v.term_ptr = ix->d.term_ptr;
@@ -932,54 +1376,72 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     v.vocab = ix->d.vocab;
     v.tile_log2 = ix->d.tile_log2;
     v.n_tiles = ix->d.n_tiles;
+    const int dbg = ix->opts.reserved;
 
     const bool prof = ix->opts.profile != 0;
     hipEvent_t *ev = nullptr;
     if (prof) {
         if (!ix->ev) {
-            ix->ev = new (std::nothrow) hipEvent_t[3 * PROF_SLOTS];
+            ix->ev = new (std::nothrow) hipEvent_t[PROF_EVENTS * PROF_SLOTS];
             if (!ix->ev) return fail(SRX_ERR_NOMEM, "srx_search: host allocation failed%s");
-            for (int i = 0; i < 3 * PROF_SLOTS; ++i) HIP_TRY(hipEventCreate(&ix->ev[i]));
+            for (int i = 0; i < PROF_EVENTS * PROF_SLOTS; ++i) HIP_TRY(hipEventCreate(&ix->ev[i]));
         }
-        ev = ix->ev + 3 * (int)(ix->ev_calls % PROF_SLOTS);
-        HIP_TRY(hipEventRecord(ev[0], stream));
+        ev = ix->ev + PROF_EVENTS * (int)(ix->ev_calls % PROF_SLOTS);
     }
+    HIP_TRY(hipMemsetAsync(ovf, 0, (size_t)nq * p.ovf_words * 4, stream));
+    if (prof) HIP_TRY(hipEventRecord(ev[0], stream));
+    // tier 1: one wavefront per (query, split)
     if (ix->d.val_type == SRX_VAL_F32)
-        hipLaunchKernelGGL(srx_score_kernel<float>, dim3((unsigned)lists), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, cand_doc, cand_score, cand_count);
+        hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
+                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, cand_doc,
+                           cand_score, cand_count);
     else
-        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3((unsigned)lists), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, cand_doc, cand_score, cand_count);
+        hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
+                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, cand_doc,
+                           cand_score, cand_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
+    // tier 2: flagged units, long queries, k > 128
+    if (ix->d.val_type == SRX_VAL_F32)
+        hipLaunchKernelGGL(srx_score_kernel<float>, dim3((unsigned)blocks), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
+                           cand_doc, cand_score, cand_count);
+    else
+        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3((unsigned)blocks), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
+                           cand_doc, cand_score, cand_count);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
-                       p.n_splits, k, p.n_splits, 1, 1, 0, ix->d.doc_base, out_doc, out_score, out_count);
+                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, ix->d.doc_base, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
     if (prof) {
-        HIP_TRY(hipEventRecord(ev[2], stream));
+        HIP_TRY(hipEventRecord(ev[3], stream));
         ++ix->ev_calls;
         if (ix->ev_n < PROF_SLOTS) ++ix->ev_n;
     }
     return SRX_OK;
 }
 
-SRX_API int srx_profile_read(srx_index *ix, float *h_ms3) {
-    if (!ix || !h_ms3) return fail(SRX_ERR_INVALID, "srx_profile_read: null argument%s");
+SRX_API int srx_profile_read(srx_index *ix, float *h_ms4) {
+    if (!ix || !h_ms4) return fail(SRX_ERR_INVALID, "srx_profile_read: null argument%s");
     if (ix->ev_n == 0 || !ix->ev) return fail(SRX_ERR_INVALID, "srx_profile_read: no profiled srx_search has run%s");
-    double acc[3] = {0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
     for (int i = 0; i < ix->ev_n; ++i) {
         const int slot = (int)((ix->ev_calls - 1 - i) % PROF_SLOTS);
-        hipEvent_t *ev = ix->ev + 3 * slot;
-        float a = 0, b = 0, c = 0;
-        HIP_TRY(hipEventSynchronize(ev[2]));
+        hipEvent_t *ev = ix->ev + PROF_EVENTS * slot;
+        float a = 0, b = 0, c = 0, d = 0;
+        HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
         HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
-        HIP_TRY(hipEventElapsedTime(&c, ev[0], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c, ev[2], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&d, ev[0], ev[3]));
         acc[0] += a;
         acc[1] += b;
         acc[2] += c;
+        acc[3] += d;
     }
-    for (int j = 0; j < 3; ++j) h_ms3[j] = (float)(acc[j] / ix->ev_n);
+    for (int j = 0; j < 4; ++j) h_ms4[j] = (float)(acc[j] / ix->ev_n);
     const int n = ix->ev_n;
     ix->ev_n = 0;
     return n;

@@ -244,8 +244,9 @@ class DeviceIndex:
                             avgdl=hi.avgdl, **kw)
 
     # -- search ----------------------------------------------------------------------------------------
-    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False) -> None:
-        self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile))
+    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0) -> None:
+        self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile),
+                                      reserved=int(debug))
         _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
 
     def workspace_bytes(self, nq: int, k: int) -> int:
@@ -287,9 +288,9 @@ class DeviceIndex:
 
     def profile_read(self):
         """Average kernel durations (ms) over the profiled searches since the last read."""
-        ms = (ctypes.c_float * 3)()
+        ms = (ctypes.c_float * 4)()
         n = _capi.check(_capi.lib().srx_profile_read(self._h, ms), "srx_profile_read")
-        return {"score_ms": ms[0], "merge_ms": ms[1], "total_ms": ms[2], "calls": n}
+        return {"wave_ms": ms[0], "block_ms": ms[1], "merge_ms": ms[2], "total_ms": ms[3], "calls": n}
 
     def device_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf))

@@ -138,10 +138,10 @@ def test_uniform_sparse_hash_path(rx):
     _, idf, avgdl = synth.corpus_stats(c)
     q = synth.queries_np(256, c.vocab, 8, seed=77)
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=12)
-    for sl, tb in ((0, 0), (12, 0), (16, 1), (14, 100000)):
-        ix.set_opts(supertile_log2=sl, target_blocks=tb)
-        for k in (100, 10):
-            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"uniform sl={sl} tb={tb} k={k}")
+    for sl, tb, dbg in ((0, 0, 0), (12, 0, 0), (16, 1, 0), (14, 100000, 0), (0, 0, 8), (17, 0, 8), (18, 0, 0)):
+        ix.set_opts(supertile_log2=sl, target_blocks=tb, debug=dbg)  # debug=8: everything through the tier-2 block kernel
+        for k in (100, 10, 128, 129):
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"uniform sl={sl} tb={tb} dbg={dbg} k={k}")
     ix.close()
 
 
@@ -154,10 +154,10 @@ def test_zipf_dense_and_overflow_paths(rx):
     assert idf.min() < 0 and df.max() > 0.9 * c.n_docs
     q = synth.queries_np(96, c.vocab, 8, seed=5, dist="zipf")
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=14)
-    for sl in (0, 14, 17):
-        ix.set_opts(supertile_log2=sl)
+    for sl, dbg in ((0, 0), (14, 0), (17, 0), (15, 8)):
+        ix.set_opts(supertile_log2=sl, debug=dbg)
         for k in (100, 1000, 1):
-            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf sl={sl} k={k}")
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf sl={sl} dbg={dbg} k={k}")
     ix.close()
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=10)  # small tiles: overflow packer groups several tiles per unit
     ix.set_opts(supertile_log2=16)
