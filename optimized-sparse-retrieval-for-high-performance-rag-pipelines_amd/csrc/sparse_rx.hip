@@ -60,7 +60,7 @@ constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 constexpr int W_R = 16;                     // postings per lane per unit held in registers (steps)
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
-constexpr int W_MCAP = 64;                  // ... at most this many such postings per unit (one per lane)
+constexpr int W_MCAP = 128;                 // pending postings of multi-term docs (resolved when the list fills)
 constexpr int W_LCAP = 256;                 // lazy top-k list capacity (>= W_KMAX + 64)
 constexpr int W_KMAX = 128;                 // largest k served by tier 1
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
@@ -839,6 +839,87 @@ __device__ __noinline__ unsigned wave_list_select(WaveShared &S, unsigned count,
     return T;
 }
 
+struct WaveTopk {
+    unsigned count, tau;
+};
+
+// Append candidates (one per lane at most) to the wave's lazy list, shrinking it first when it is nearly full.
+__device__ __forceinline__ void wave_append(WaveShared &S, WaveTopk &tk, int k, bool cand, unsigned bits, int doc) {
+    const int lane = threadIdx.x;
+    const unsigned long long m = __ballot(cand);
+    if (m != 0ull) {  // uniform
+        if (tk.count > (unsigned)(W_LCAP - 64)) {  // make room for up to 64 more entries
+            tk.tau = wave_list_select(S, tk.count, k);
+            tk.count = (unsigned)k;
+        }
+        const bool c2 = cand && bits >= tk.tau;  // tau may just have risen
+        const unsigned long long m2 = __ballot(c2);
+        if (c2) {
+            const unsigned p = tk.count + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
+            S.lbits[p] = bits;
+            S.ldoc[p] = doc;
+        }
+        tk.count += (unsigned)__popcll(m2);
+    }
+}
+
+// Resolve the pending postings of multi-term docs (S.ml_*, mcnt <= W_MCAP = 128 entries, two per lane): per-doc
+// sums in a small hash table, in rounds of ascending term slot (docs are unique inside a term, so a round has no
+// intra-instruction conflicts; one wave's DS instructions execute in order across rounds).  The finished sums
+// (> 0, >= tau) enter the top-k list.  Rare (once per ~30 units), hence out of line.
+__device__ __noinline__ WaveTopk wave_resolve_multi(WaveShared &S, unsigned mcnt, int k, WaveTopk tk) {
+    const int lane = threadIdx.x;
+    wsync();
+    int md[2], mt[2];
+    float mc[2];
+    unsigned h[2];
+    bool pending[2], claimed[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned i = lane + 64 * e;
+        pending[e] = i < mcnt;
+        claimed[e] = false;
+        md[e] = pending[e] ? S.ml_d[i] : 0;
+        mc[e] = pending[e] ? S.ml_c[i] : 0.f;
+        mt[e] = pending[e] ? S.ml_t[i] : 0x7FFFFFFF;
+        h[e] = ((unsigned)md[e] * 0x9E3779B1u) >> (32 - 8);
+    }
+    while (__ballot(pending[0] || pending[1]) != 0ull) {  // one round per distinct term, ascending
+        const unsigned mine = min(pending[0] ? (unsigned)mt[0] : 0x7FFFFFFFu, pending[1] ? (unsigned)mt[1] : 0x7FFFFFFFu);
+        const int tcur = uni((int)wave_min(mine));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (pending[e] && mt[e] == tcur) {
+                for (;;) {
+                    const int o = atomicCAS(&S.mkeys[h[e]], EMPTY_KEY, md[e]);
+                    if (o == EMPTY_KEY) {
+                        S.mvals[h[e]] = mc[e];  // first term of this doc (0 + c == c, c is never -0)
+                        claimed[e] = true;
+                        break;
+                    }
+                    if (o == md[e]) {
+                        S.mvals[h[e]] = S.mvals[h[e]] + mc[e];  // a later term: in-order read-add-store
+                        break;
+                    }
+                    h[e] = (h[e] + 1) & (W_MSLOTS - 1);
+                }
+                pending[e] = false;
+            }
+            wsync();
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float sc = claimed[e] ? S.mvals[h[e]] : 0.f;
+        const unsigned b = __float_as_uint(sc);
+        wave_append(S, tk, k, claimed[e] && sc > 0.0f && b >= tk.tau, b, md[e]);
+    }
+    wsync();
+    reinterpret_cast<int4 *>(S.mkeys)[lane] = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+    wsync();
+    return tk;
+}
+
 template <typename VT>
 __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                       const int32_t *__restrict__ q_term,
@@ -888,7 +969,8 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         my_qw = q_weight[t0 + tslot];
     }
     wsync();
-    unsigned count = 0, tau = 0;  // wave-uniform
+    WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
+    unsigned mcnt = 0;       // wave-uniform: pending multi-term postings in S.ml_*
 
     // unit boundary j of my term: #postings with doc < (j << super_log2)
     auto bound = [&](int j) __attribute__((always_inline)) -> int {
@@ -897,54 +979,32 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
 
     // Issue the loads of my term's run [lo, lo + len) of the unit: step r <-> posting jl + r * lpt.  Always exactly
     // 2 * W_R loads, no branches (idle lanes / steps read posting 0), so that the compiler can wait for THIS unit's
-    // data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.  Returns the number of
-    // steps the unit needs (> W_R: does not fit the registers -> nothing useful is loaded, tier 2 takes the unit).
-    auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
-        const int n_steps = (uni((int)wave_max((unsigned)len)) + lpt - 1) >> lpt_log2;
-        const int len_eff = (n_steps <= W_R) ? len : 0;
+    // data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
+    auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
         const int64_t g0 = base + lo + jl;
 #pragma unroll
         for (int r = 0; r < W_R; ++r) {
             const int p = jl + (r << lpt_log2);
-            const int64_t g = (p < len_eff) ? g0 + (r << lpt_log2) : 0;
+            const int64_t g = (p < len) ? g0 + (r << lpt_log2) : 0;
             d[r] = post_doc[g];
             v[r] = load_val(post_val, g);
-        }
-        return n_steps;
-    };
-
-    auto append = [&](bool cand, unsigned bits, int doc) __attribute__((always_inline)) {
-        const unsigned long long m = __ballot(cand);
-        if (m != 0ull) {  // uniform
-            if (count > (unsigned)(W_LCAP - 64)) {  // make room for up to 64 more entries
-                tau = wave_list_select(S, count, k);
-                count = (unsigned)k;
-            }
-            const bool c2 = cand && bits >= tau;  // tau may just have risen
-            const unsigned long long m2 = __ballot(c2);
-            if (c2) {
-                const unsigned p = count + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
-                S.lbits[p] = bits;
-                S.ldoc[p] = doc;
-            }
-            count += (unsigned)__popcll(m2);
         }
     };
 
     // Score one unit from registers.  Pass 1 sets every posting's doc bit (ds_or_rtn): a bit found already set means
     // another posting of the same doc came earlier.  Pass 2: those lanes clear the bit again, which tells the earlier
     // posting's lane too.  Pass 3: bit still set = the doc is matched by exactly one term -> its score is the single
-    // contribution 0 + c, straight from registers.  Docs matched by several terms (rare) are collected in a small
-    // LDS list and summed in a hash table in rounds of ascending term id; one wave's DS instructions execute in
-    // order, so the sum is accumulated exactly like the reference's CSR row walk.  false -> the unit goes to tier 2.
-    auto process = [&](int su, int len, int n_steps, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+    // contribution 0 + c, straight from registers.  Postings of docs matched by several terms (rare) are parked in an
+    // LDS list and resolved in bulk by wave_resolve_multi (ascending term order).  No cross-lane shuffles here: all
+    // bookkeeping is ballots on the scalar unit.  false -> the unit goes to tier 2.
+    auto process = [&](int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
         const int ubase = su << super_log2;
         unsigned old[W_R];
         unsigned valid = 0;
 #pragma unroll
         for (int r = 0; r < W_R; ++r) {
-            if (r < n_steps) {  // uniform
-                const bool ok = jl + (r << lpt_log2) < len;
+            const bool ok = jl + (r << lpt_log2) < len;
+            if (__ballot(ok) != 0ull) {  // uniform
                 if (ok) valid |= 1u << r;
                 const unsigned off = (unsigned)(d[r] - ubase);
                 const unsigned w = ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane);
@@ -954,50 +1014,54 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         unsigned dup = 0;
 #pragma unroll
         for (int r = 0; r < W_R; ++r) {
-            if (r < n_steps) {
-                const unsigned off = (unsigned)(d[r] - ubase);
-                if (((valid >> r) & 1u) && ((old[r] >> (off & 31)) & 1u)) dup |= 1u << r;
-            }
+            const unsigned off = (unsigned)(d[r] - ubase);
+            if (((valid >> r) & 1u) && ((old[r] >> (off & 31)) & 1u)) dup |= 1u << r;
         }
-        const bool any_dup = __ballot(dup != 0) != 0ull;  // uniform
-        unsigned multi = 0;
-        if (any_dup) {
+        unsigned multi = 0, n_multi = 0;
+        if (__ballot(dup != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                const unsigned off = (unsigned)(d[r] - ubase);
-                if ((dup >> r) & 1u) atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                const bool dp = (dup >> r) & 1u;
+                if (__ballot(dp) != 0ull) {
+                    const unsigned off = (unsigned)(d[r] - ubase);
+                    if (dp) atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                }
             }
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                if (r < n_steps) {
-                    const bool ok = (valid >> r) & 1u;
+                const bool ok = (valid >> r) & 1u;
+                if (__ballot(ok) != 0ull) {
                     const unsigned off = (unsigned)(d[r] - ubase);
                     const unsigned x = S.bm[ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)];
-                    if (ok && !((x >> (off & 31)) & 1u)) multi |= 1u << r;
+                    const bool mu = ok && !((x >> (off & 31)) & 1u);
+                    if (mu) multi |= 1u << r;
+                    n_multi += (unsigned)__popcll(__ballot(mu));
                 }
             }
         }
         // restore the bitmap (every touched word back to 0)
 #pragma unroll
         for (int r = 0; r < W_R; ++r) {
-            if (r < n_steps) {
+            const bool ok = (valid >> r) & 1u;
+            if (__ballot(ok) != 0ull) {
                 const unsigned off = (unsigned)(d[r] - ubase);
-                S.bm[((valid >> r) & 1u) ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)] = 0u;
+                S.bm[ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)] = 0u;
             }
         }
-        const unsigned n_multi = any_dup ? uniu(wave_sum((unsigned)__popc(multi))) : 0u;
         if (n_multi > (unsigned)W_MCAP) return false;
         if (dbg & 2) return true;
-
-        unsigned mcnt = 0;  // uniform: entries in the multi list
+        if (mcnt + n_multi > (unsigned)W_MCAP) {  // uniform: make room in the pending list
+            tk = wave_resolve_multi(S, mcnt, k, tk);
+            mcnt = 0;
+        }
 #pragma unroll
         for (int r = 0; r < W_R; ++r) {
-            if (r < n_steps) {
+            const bool ok = (valid >> r) & 1u;
+            if (__ballot(ok) != 0ull) {
                 const float c = 0.0f + (v[r] * my_idf) * my_qw;
                 const unsigned b = __float_as_uint(c);
-                const bool ok = (valid >> r) & 1u;
                 const bool mu = (multi >> r) & 1u;
-                if (!(dbg & 1)) append(ok && !mu && c > 0.0f && b >= tau, b, d[r]);  // docs matched by a single term
+                if (!(dbg & 1)) wave_append(S, tk, k, ok && !mu && c > 0.0f && b >= tk.tau, b, d[r]);  // single-term docs
                 if (n_multi > 0) {  // uniform
                     const unsigned long long mm = __ballot(mu);
                     if (mm != 0ull) {
@@ -1012,43 +1076,6 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 }
             }
         }
-        if (n_multi > 0) {
-            wsync();
-            const bool mine = (unsigned)lane < mcnt;  // W_MCAP == 64: one list entry per lane
-            const int md = mine ? S.ml_d[lane] : 0;
-            const float mc = mine ? S.ml_c[lane] : 0.f;
-            const int mt = mine ? S.ml_t[lane] : 0x7FFFFFFF;
-            bool pending = mine, claimed = false;
-            unsigned h = ((unsigned)md * 0x9E3779B1u) >> (32 - 8);
-            while (__ballot(pending) != 0ull) {  // one round per distinct term, ascending
-                const int tcur = uni((int)wave_min(pending ? (unsigned)mt : 0x7FFFFFFFu));
-                if (pending && mt == tcur) {  // docs are unique inside one term
-                    for (;;) {
-                        const int o = atomicCAS(&S.mkeys[h], EMPTY_KEY, md);
-                        if (o == EMPTY_KEY) {
-                            S.mvals[h] = mc;  // first term of this doc
-                            claimed = true;
-                            break;
-                        }
-                        if (o == md) {
-                            S.mvals[h] = S.mvals[h] + mc;  // a later term: in-order read-add-store
-                            break;
-                        }
-                        h = (h + 1) & (W_MSLOTS - 1);
-                    }
-                    pending = false;
-                }
-                wsync();
-            }
-            if (!(dbg & 1)) {
-                const float sc = claimed ? S.mvals[h] : 0.f;
-                const unsigned b = __float_as_uint(sc);
-                append(claimed && sc > 0.0f && b >= tau, b, md);
-            }
-            wsync();
-            reinterpret_cast<int4 *>(S.mkeys)[lane] = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
-            wsync();
-        }
         return true;
     };
 
@@ -1061,29 +1088,31 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     int dA[W_R], dB[W_R];
     float vA[W_R], vB[W_R];
     int b0 = bound(su_lo), b1 = bound(su_lo + 1), b2 = bound(su_lo + 2);  // b_j = boundary j; unit u = [b_u, b_{u+1})
-    int lenA = b1 - b0, lenB = 0, nA = 0, nB = 0;
-    if (su_lo >= su_hi) lenA = 0;
-    nA = issue(b0, lenA, dA, vA);
-    // one stage: unit su is in (lenc, nc, d, v); unit su+1 goes to (lenn, nn, dn, vn)
-    auto stage = [&](int su, int lenc, int nc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int &nn,
-                     int (&dn)[W_R], float (&vn)[W_R]) __attribute__((always_inline)) {
+    int lenA = (su_lo < su_hi) ? b1 - b0 : 0, lenB = 0;
+    issue(b0, (__ballot(lenA > W_R * lpt) == 0ull) ? lenA : 0, dA, vA);
+    // one stage: unit su is in (lenc, d, v); unit su+1 goes to (lenn, dn, vn)
+    auto stage = [&](int su, int lenc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int (&dn)[W_R],
+                     float (&vn)[W_R]) __attribute__((always_inline)) {
         const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
         lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
-        nn = issue(b1, lenn, dn, vn);
-        if (nc > W_R) {
+        const bool fitn = __ballot(lenn > W_R * lpt) == 0ull;  // uniform: every term's run fits W_R steps
+        issue(b1, fitn ? lenn : 0, dn, vn);
+        if (__ballot(lenc > W_R * lpt) != 0ull) {
             flag_tier2(su);
-        } else if (nc > 0) {
-            if (!process(su, lenc, nc, d, v)) flag_tier2(su);
+        } else if (__ballot(lenc > 0) != 0ull) {
+            if (!process(su, lenc, d, v)) flag_tier2(su);
         }
         b1 = b2;
         b2 = b3;
     };
     for (int su = su_lo; su < su_hi; su += 2) {
-        stage(su, lenA, nA, dA, vA, lenB, nB, dB, vB);
-        if (su + 1 < su_hi) stage(su + 1, lenB, nB, dB, vB, lenA, nA, dA, vA);
+        stage(su, lenA, dA, vA, lenB, dB, vB);
+        if (su + 1 < su_hi) stage(su + 1, lenB, dB, vB, lenA, dA, vA);
     }
+    if (mcnt > 0) tk = wave_resolve_multi(S, mcnt, k, tk);
+    unsigned count = tk.count;
     if (count > (unsigned)k) {
-        tau = wave_list_select(S, count, k);
+        wave_list_select(S, count, k);
         count = (unsigned)k;
     }
     const int64_t o = list * k;
