@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 #include <new>
 
 #include "sparse_rx.h"
@@ -57,7 +58,7 @@ constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
 constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
-constexpr int W_R = 16;                     // postings per lane per unit held in registers (steps)
+constexpr int W_R = 12;                     // postings per lane per unit held in registers (steps)
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
 constexpr int W_MCAP = 128;                 // pending postings of multi-term docs (resolved when the list fills)
@@ -704,7 +705,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct WaveShared {
-    unsigned bm[W_BM_WORDS + 64];  // doc bitmap of the current unit (1 bit per doc) + one dummy word per lane
+    unsigned bm[W_BM_WORDS];       // doc bitmap of the current unit (1 bit per doc)
     int mkeys[W_MSLOTS];           // small hash table for docs matched by more than one query term
     float mvals[W_MSLOTS];
     unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
@@ -920,6 +921,11 @@ __device__ __noinline__ WaveTopk wave_resolve_multi(WaveShared &S, unsigned mcnt
     return tk;
 }
 
+template <int L>
+struct IntC {
+    static constexpr int value = L;
+};
+
 template <typename VT>
 __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                       const int32_t *__restrict__ q_term,
@@ -944,120 +950,121 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
     const int tps_log2 = super_log2 - ix.tile_log2;
     const int row = ix.n_tiles + 1;
-    const int32_t *post_doc = ix.post_doc;
-    const VT *post_val = reinterpret_cast<const VT *>(ix.post_val);
 
-    for (int i = lane; i < (W_BM_WORDS + 64) / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < W_BM_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
-    // Query term t owns a group of lpt = 64 / 2^ceil(log2 nt) lanes; lane j of the group handles postings
-    // j, j + lpt, j + 2 lpt, ... of the term's run inside the unit.  Term data stays in registers.
-    int lg = 0;
-    while ((1 << lg) < nt) ++lg;
-    const int lpt_log2 = 6 - lg;
-    const int lpt = 1 << lpt_log2;
-    const int tslot = lane >> lpt_log2;  // my term slot (ascending term id)
-    const int jl = lane & (lpt - 1);
-    const bool has_term = tslot < nt;
-    int64_t base = 0;
-    const int32_t *skip_row = ix.tile_skip;
-    float my_idf = 0.f, my_qw = 0.f;
-    if (has_term) {
-        const int term = q_term[t0 + tslot];
-        base = ix.term_ptr[term];
-        skip_row = ix.tile_skip + (int64_t)term * row;
-        my_idf = ix.idf[term];
-        my_qw = q_weight[t0 + tslot];
-    }
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
     unsigned mcnt = 0;       // wave-uniform: pending multi-term postings in S.ml_*
+    int lg = 0;
+    while ((1 << lg) < nt) ++lg;
 
-    // unit boundary j of my term: #postings with doc < (j << super_log2)
-    auto bound = [&](int j) __attribute__((always_inline)) -> int {
-        return has_term ? skip_row[min(j << tps_log2, ix.n_tiles)] : 0;
-    };
+    // Query term t owns a group of LPT = 64 / 2^ceil(log2 nt) lanes; lane jl of the group handles postings
+    // jl, jl + LPT, jl + 2 LPT, ... of the term's run inside the unit.  Term data stays in registers.  LPT is a
+    // compile-time constant of the body (7 instantiations): loads use immediate offsets, no per-step address math.
+    auto run = [&](auto lconst) __attribute__((always_inline)) {
+        constexpr int LPT_LOG2 = decltype(lconst)::value;
+        constexpr int LPT = 1 << LPT_LOG2;
+        const int tslot = lane >> LPT_LOG2;  // my term slot (ascending term id)
+        const int jl = lane & (LPT - 1);
+        const bool has_term = tslot < nt;
+        int64_t base = 0;
+        const int32_t *skip_row = ix.tile_skip;
+        float my_idf = 0.f, my_qw = 0.f;
+        if (has_term) {
+            const int term = q_term[t0 + tslot];
+            base = ix.term_ptr[term];
+            skip_row = ix.tile_skip + (int64_t)term * row;
+            my_idf = ix.idf[term];
+            my_qw = q_weight[t0 + tslot];
+        }
+        const int32_t *const doc0 = ix.post_doc;
+        const VT *const val0 = reinterpret_cast<const VT *>(ix.post_val);
 
-    // Issue the loads of my term's run [lo, lo + len) of the unit: step r <-> posting jl + r * lpt.  Always exactly
-    // 2 * W_R loads, no branches (idle lanes / steps read posting 0), so that the compiler can wait for THIS unit's
-    // data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
-    auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
-        const int64_t g0 = base + lo + jl;
-#pragma unroll
-        for (int r = 0; r < W_R; ++r) {
-            const int p = jl + (r << lpt_log2);
-            const int64_t g = (p < len) ? g0 + (r << lpt_log2) : 0;
-            d[r] = post_doc[g];
-            v[r] = load_val(post_val, g);
-        }
-    };
+        // unit boundary j of my term: #postings with doc < (j << super_log2)
+        auto bound = [&](int j) __attribute__((always_inline)) -> int {
+            return has_term ? skip_row[min(j << tps_log2, ix.n_tiles)] : 0;
+        };
 
-    // Score one unit from registers.  Pass 1 sets every posting's doc bit (ds_or_rtn): a bit found already set means
-    // another posting of the same doc came earlier.  Pass 2: those lanes clear the bit again, which tells the earlier
-    // posting's lane too.  Pass 3: bit still set = the doc is matched by exactly one term -> its score is the single
-    // contribution 0 + c, straight from registers.  Postings of docs matched by several terms (rare) are parked in an
-    // LDS list and resolved in bulk by wave_resolve_multi (ascending term order).  No cross-lane shuffles here: all
-    // bookkeeping is ballots on the scalar unit.  false -> the unit goes to tier 2.
-    auto process = [&](int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
-        const int ubase = su << super_log2;
-        unsigned old[W_R];
-        unsigned valid = 0;
-#pragma unroll
-        for (int r = 0; r < W_R; ++r) {
-            const bool ok = jl + (r << lpt_log2) < len;
-            if (__ballot(ok) != 0ull) {  // uniform
-                if (ok) valid |= 1u << r;
-                const unsigned off = (unsigned)(d[r] - ubase);
-                const unsigned w = ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane);
-                old[r] = atomicOr(&S.bm[w], ok ? (1u << (off & 31)) : 0u);
-            }
-        }
-        unsigned dup = 0;
-#pragma unroll
-        for (int r = 0; r < W_R; ++r) {
-            const unsigned off = (unsigned)(d[r] - ubase);
-            if (((valid >> r) & 1u) && ((old[r] >> (off & 31)) & 1u)) dup |= 1u << r;
-        }
-        unsigned multi = 0, n_multi = 0;
-        if (__ballot(dup != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms
+        // Issue the loads of my term's run [lo, lo + len) of the unit: step r <-> posting jl + r * LPT.  Always
+        // exactly 2 * W_R loads, no branches (idle lanes / steps read posting 0), so that the compiler can wait
+        // for THIS unit's data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
+        auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
+            const int32_t *dp = doc0 + (base + lo + jl);
+            const VT *vp = val0 + (base + lo + jl);
+            const int rem = len - jl;  // step r is mine iff r * LPT < rem
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                const bool dp = (dup >> r) & 1u;
-                if (__ballot(dp) != 0ull) {
+                // idle -> posting 0: the dummy pointer is pre-biased so that both cases use the same immediate offset
+                const bool ok = (r << LPT_LOG2) < rem;
+                d[r] = (ok ? dp : doc0 - (r << LPT_LOG2))[r << LPT_LOG2];
+                v[r] = load_val(ok ? vp : val0 - (r << LPT_LOG2), r << LPT_LOG2);
+            }
+        };
+
+        // Score one unit from registers.  Pass 1 sets every posting's doc bit (ds_or_rtn): a bit found already set
+        // means another posting of the same doc came earlier.  Pass 2: those lanes clear the bit again, which tells
+        // the earlier posting's lane too.  Pass 3: bit still set = the doc is matched by exactly one term -> its
+        // score is the single contribution 0 + c, straight from registers.  Postings of docs matched by several
+        // terms (rare) are parked in an LDS list and resolved in bulk by wave_resolve_multi (ascending term order).
+        // No cross-lane shuffles here: all bookkeeping is ballots on the scalar unit.  false -> tier 2.
+        auto process = [&](int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+            const int ubase = su << super_log2;
+            const int rem = len - jl;
+            unsigned old[W_R];
+#pragma unroll
+            for (int r = 0; r < W_R; ++r) {
+                const bool ok = (r << LPT_LOG2) < rem;
+                old[r] = 0u;
+                if (ok) {
                     const unsigned off = (unsigned)(d[r] - ubase);
-                    if (dp) atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                    old[r] = atomicOr(&S.bm[off >> 5], 1u << (off & 31));
                 }
             }
+            unsigned dup = 0;
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                const bool ok = (valid >> r) & 1u;
-                if (__ballot(ok) != 0ull) {
-                    const unsigned off = (unsigned)(d[r] - ubase);
-                    const unsigned x = S.bm[ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)];
-                    const bool mu = ok && !((x >> (off & 31)) & 1u);
+                const unsigned off = (unsigned)(d[r] - ubase);
+                if ((old[r] >> (off & 31)) & 1u) dup |= 1u << r;  // old == 0 for idle steps
+            }
+            unsigned multi = 0, n_multi = 0;
+            if (__ballot(dup != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms
+#pragma unroll
+                for (int r = 0; r < W_R; ++r) {
+                    if ((dup >> r) & 1u) {
+                        const unsigned off = (unsigned)(d[r] - ubase);
+                        atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < W_R; ++r) {
+                    const bool ok = (r << LPT_LOG2) < rem;
+                    bool mu = false;
+                    if (ok) {
+                        const unsigned off = (unsigned)(d[r] - ubase);
+                        mu = !((S.bm[off >> 5] >> (off & 31)) & 1u);
+                    }
                     if (mu) multi |= 1u << r;
                     n_multi += (unsigned)__popcll(__ballot(mu));
                 }
             }
-        }
-        // restore the bitmap (every touched word back to 0)
+            // restore the bitmap (every touched word back to 0)
 #pragma unroll
-        for (int r = 0; r < W_R; ++r) {
-            const bool ok = (valid >> r) & 1u;
-            if (__ballot(ok) != 0ull) {
-                const unsigned off = (unsigned)(d[r] - ubase);
-                S.bm[ok ? (off >> 5) : (unsigned)(W_BM_WORDS + lane)] = 0u;
+            for (int r = 0; r < W_R; ++r) {
+                if ((r << LPT_LOG2) < rem) {
+                    const unsigned off = (unsigned)(d[r] - ubase);
+                    S.bm[off >> 5] = 0u;
+                }
             }
-        }
-        if (n_multi > (unsigned)W_MCAP) return false;
-        if (dbg & 2) return true;
-        if (mcnt + n_multi > (unsigned)W_MCAP) {  // uniform: make room in the pending list
-            tk = wave_resolve_multi(S, mcnt, k, tk);
-            mcnt = 0;
-        }
+            if (n_multi > (unsigned)W_MCAP) return false;
+            if (dbg & 2) return true;
+            if (mcnt + n_multi > (unsigned)W_MCAP) {  // uniform: make room in the pending list
+                tk = wave_resolve_multi(S, mcnt, k, tk);
+                mcnt = 0;
+            }
 #pragma unroll
-        for (int r = 0; r < W_R; ++r) {
-            const bool ok = (valid >> r) & 1u;
-            if (__ballot(ok) != 0ull) {
+            for (int r = 0; r < W_R; ++r) {
+                const bool ok = (r << LPT_LOG2) < rem;
                 const float c = 0.0f + (v[r] * my_idf) * my_qw;
                 const unsigned b = __float_as_uint(c);
                 const bool mu = (multi >> r) & 1u;
@@ -1075,39 +1082,48 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     }
                 }
             }
-        }
-        return true;
-    };
+            return true;
+        };
 
-    auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
-        if (lane == 0) atomicOr(&ovf[(int64_t)q * ovf_words + (su >> 5)], 1u << (su & 31));
-    };
+        auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
+            if (lane == 0) atomicOr(&ovf[(int64_t)q * ovf_words + (su >> 5)], 1u << (su & 31));
+        };
 
-    // ---- software pipeline over units, unrolled by two (register sets A / B alternate): issue the loads of unit
-    //      u+1, then score unit u from registers ----
-    int dA[W_R], dB[W_R];
-    float vA[W_R], vB[W_R];
-    int b0 = bound(su_lo), b1 = bound(su_lo + 1), b2 = bound(su_lo + 2);  // b_j = boundary j; unit u = [b_u, b_{u+1})
-    int lenA = (su_lo < su_hi) ? b1 - b0 : 0, lenB = 0;
-    issue(b0, (__ballot(lenA > W_R * lpt) == 0ull) ? lenA : 0, dA, vA);
-    // one stage: unit su is in (lenc, d, v); unit su+1 goes to (lenn, dn, vn)
-    auto stage = [&](int su, int lenc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int (&dn)[W_R],
-                     float (&vn)[W_R]) __attribute__((always_inline)) {
-        const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
-        lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
-        const bool fitn = __ballot(lenn > W_R * lpt) == 0ull;  // uniform: every term's run fits W_R steps
-        issue(b1, fitn ? lenn : 0, dn, vn);
-        if (__ballot(lenc > W_R * lpt) != 0ull) {
-            flag_tier2(su);
-        } else if (__ballot(lenc > 0) != 0ull) {
-            if (!process(su, lenc, d, v)) flag_tier2(su);
+        // ---- software pipeline over units, unrolled by two (register sets A / B alternate): issue the loads of
+        //      unit u+1, then score unit u from registers ----
+        int dA[W_R], dB[W_R];
+        float vA[W_R], vB[W_R];
+        int b0 = bound(su_lo), b1 = bound(su_lo + 1), b2 = bound(su_lo + 2);  // b_j = boundary j; unit u = [b_u, b_{u+1})
+        int lenA = (su_lo < su_hi) ? b1 - b0 : 0, lenB = 0;
+        issue(b0, (__ballot(lenA > W_R * LPT) == 0ull) ? lenA : 0, dA, vA);
+        // one stage: unit su is in (lenc, d, v); unit su+1 goes to (lenn, dn, vn)
+        auto stage = [&](int su, int lenc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int (&dn)[W_R],
+                         float (&vn)[W_R]) __attribute__((always_inline)) {
+            const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
+            lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
+            const bool fitn = __ballot(lenn > W_R * LPT) == 0ull;  // uniform: every term's run fits W_R steps
+            issue(b1, fitn ? lenn : 0, dn, vn);
+            if (__ballot(lenc > W_R * LPT) != 0ull) {
+                flag_tier2(su);
+            } else if (__ballot(lenc > 0) != 0ull) {
+                if (!process(su, lenc, d, v)) flag_tier2(su);
+            }
+            b1 = b2;
+            b2 = b3;
+        };
+        for (int su = su_lo; su < su_hi; su += 2) {
+            stage(su, lenA, dA, vA, lenB, dB, vB);
+            if (su + 1 < su_hi) stage(su + 1, lenB, dB, vB, lenA, dA, vA);
         }
-        b1 = b2;
-        b2 = b3;
     };
-    for (int su = su_lo; su < su_hi; su += 2) {
-        stage(su, lenA, dA, vA, lenB, dB, vB);
-        if (su + 1 < su_hi) stage(su + 1, lenB, dB, vB, lenA, dA, vA);
+    switch (6 - lg) {
+        case 0: run(IntC<0>{}); break;
+        case 1: run(IntC<1>{}); break;
+        case 2: run(IntC<2>{}); break;
+        case 3: run(IntC<3>{}); break;
+        case 4: run(IntC<4>{}); break;
+        case 5: run(IntC<5>{}); break;
+        default: run(IntC<6>{}); break;
     }
     if (mcnt > 0) tk = wave_resolve_multi(S, mcnt, k, tk);
     unsigned count = tk.count;
@@ -1341,8 +1357,9 @@ struct Plan {
     int super_log2, n_super, n_splits, ovf_words, lists_per_q;
 };
 
-// Supertile (unit) = the doc range one tier-1 hash unit covers.  Auto rule: the largest power of two
-// (tile .. tile*64) for which an 8-term query of average terms is expected to stay under ~55 % of W_CAP.
+// Supertile (unit) = the doc range one tier-1 unit covers (<= 2^W_UNIT_LOG2 docs, the wave bitmap).  Auto rule: the
+// largest power of two (tile .. tile*64) for which the run of an average term inside a unit fits the registers of
+// its lane group in the reference case of an 8-term query (8 lanes x W_R steps), with a 3.5-sigma Poisson margin.
 Plan make_plan(const srx_index *ix, int nq, int k) {
     Plan p;
     const srx_index_desc &d = ix->d;
@@ -1350,7 +1367,11 @@ Plan make_plan(const srx_index *ix, int nq, int k) {
     if (sl == 0) {
         const double per_doc_per_term = (double)d.nnz / ((double)d.n_docs * (double)d.vocab);  // E[postings of a term per doc]
         sl = d.tile_log2;
-        while (sl < d.tile_log2 + 6 && sl < W_UNIT_LOG2 && 8.0 * per_doc_per_term * (double)(2ll << sl) <= 0.6 * W_CAP) ++sl;
+        auto fits = [&](int l) {
+            const double mean = per_doc_per_term * (double)(1ll << l);
+            return mean + 3.5 * sqrt(mean) <= 8.0 * W_R;
+        };
+        while (sl < d.tile_log2 + 6 && sl < W_UNIT_LOG2 && fits(sl + 1)) ++sl;
     }
     p.super_log2 = sl;
     p.n_super = (int)((d.n_docs + (1ll << sl) - 1) >> sl);
