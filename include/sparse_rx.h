@@ -53,6 +53,8 @@ typedef enum {
 /* Limits of this build (srx_limits() returns them at run time). */
 #define SRX_MAX_K 1024         /* largest top-k */
 #define SRX_MAX_TILE_LOG2 14   /* skip-table granularity G = 2^tile_log2 docs, G <= 16384 */
+#define SRX_POST_PAD 16         /* post_doc / post_val must be readable up to this many elements past nnz
+                                  (vector loads of 4 postings may run past a list's end; the values are ignored) */
 
 /*
  * Device-resident inverted index of one doc-range shard (term-major CSC + tile skip table).
@@ -76,8 +78,8 @@ typedef struct {
     int32_t tile_log2; /* G = 1 << tile_log2, <= SRX_MAX_TILE_LOG2 */
     int32_t n_tiles;   /* ceil(n_docs / G) */
     const int64_t *term_ptr;  /* [vocab+1] */
-    const int32_t *post_doc;  /* [nnz] */
-    const void *post_val;     /* [nnz] f32 or f16 */
+    const int32_t *post_doc;  /* [nnz + SRX_POST_PAD] */
+    const void *post_val;     /* [nnz + SRX_POST_PAD] f32 or f16 */
     const int32_t *tile_skip; /* [vocab*(n_tiles+1)] */
     const float *idf;         /* [vocab] */
 } srx_index_desc;

@@ -351,6 +351,29 @@ __device__ void topk_shrink(int k, TopkShared &tk, unsigned *hist) {
     topk_fold<1, false>(none_b, none_d, k, tk, hist);
 }
 
+// 4 consecutive postings with one instruction (global_load_dwordx4 / dwordx2); only 4-byte alignment is guaranteed
+struct __attribute__((packed, aligned(4))) PackI4 {
+    int x, y, z, w;
+};
+struct __attribute__((packed, aligned(4))) PackF4 {
+    float x, y, z, w;
+};
+struct __attribute__((packed, aligned(2))) PackH4 {
+    __half x, y, z, w;
+};
+__device__ __forceinline__ void load4(const int32_t *p, int elem_off, int &a, int &b, int &c, int &d) {
+    const PackI4 t = *reinterpret_cast<const PackI4 *>(p + elem_off);
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ __forceinline__ void load4(const float *p, int elem_off, float &a, float &b, float &c, float &d) {
+    const PackF4 t = *reinterpret_cast<const PackF4 *>(p + elem_off);
+    a = t.x; b = t.y; c = t.z; d = t.w;
+}
+__device__ __forceinline__ void load4(const __half *p, int elem_off, float &a, float &b, float &c, float &d) {
+    const PackH4 t = *reinterpret_cast<const PackH4 *>(p + elem_off);
+    a = __half2float(t.x); b = __half2float(t.y); c = __half2float(t.z); d = __half2float(t.w);
+}
+
 __device__ __forceinline__ float load_val(const float *p, int64_t i) { return p[i]; }
 __device__ __forceinline__ float load_val(const __half *p, int64_t i) { return __half2float(p[i]); }
 
@@ -956,6 +979,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
     unsigned mcnt = 0;       // wave-uniform: pending multi-term postings in S.ml_*
+    int sink = 0;            // debug only
     int lg = 0;
     while ((1 << lg) < nt) ++lg;
 
@@ -986,19 +1010,21 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             return has_term ? skip_row[min(j << tps_log2, ix.n_tiles)] : 0;
         };
 
-        // Issue the loads of my term's run [lo, lo + len) of the unit: step r <-> posting jl + r * LPT.  Always
-        // exactly 2 * W_R loads, no branches (idle lanes / steps read posting 0), so that the compiler can wait
-        // for THIS unit's data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
+        // Issue the loads of my term's run [lo, lo + len) of the unit.  A lane loads 4 consecutive postings per step
+        // (dwordx4: the group's LPT lanes read 16 * LPT contiguous bytes, whole cache lines): register r = 4 s + i
+        // holds posting (s * LPT + jl) * 4 + i.  Always exactly 2 * W_R / 4 loads, no branches (idle lanes read
+        // postings 0..3 through a pre-biased dummy pointer, same immediate offset), so that the compiler can wait for
+        // THIS unit's data with a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
         auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
-            const int32_t *dp = doc0 + (base + lo + jl);
-            const VT *vp = val0 + (base + lo + jl);
-            const int rem = len - jl;  // step r is mine iff r * LPT < rem
+            const int32_t *dp = doc0 + (base + lo + 4 * jl);
+            const VT *vp = val0 + (base + lo + 4 * jl);
+            const int rem = len - 4 * jl;  // register r is mine iff pos(r) < rem, pos(r) = (r / 4) * 4 LPT + r % 4
 #pragma unroll
-            for (int r = 0; r < W_R; ++r) {
-                // idle -> posting 0: the dummy pointer is pre-biased so that both cases use the same immediate offset
-                const bool ok = (r << LPT_LOG2) < rem;
-                d[r] = (ok ? dp : doc0 - (r << LPT_LOG2))[r << LPT_LOG2];
-                v[r] = load_val(ok ? vp : val0 - (r << LPT_LOG2), r << LPT_LOG2);
+            for (int s4 = 0; s4 < W_R / 4; ++s4) {
+                const int eo = s4 << (LPT_LOG2 + 2);
+                const bool ok = eo < rem;
+                load4(ok ? dp : doc0 - eo, eo, d[4 * s4], d[4 * s4 + 1], d[4 * s4 + 2], d[4 * s4 + 3]);
+                load4(ok ? vp : val0 - eo, eo, v[4 * s4], v[4 * s4 + 1], v[4 * s4 + 2], v[4 * s4 + 3]);
             }
         };
 
@@ -1010,11 +1036,11 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         // No cross-lane shuffles here: all bookkeeping is ballots on the scalar unit.  false -> tier 2.
         auto process = [&](int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
             const int ubase = su << super_log2;
-            const int rem = len - jl;
+            const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
             unsigned old[W_R];
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                const bool ok = (r << LPT_LOG2) < rem;
+                const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
                 old[r] = 0u;
                 if (ok) {
                     const unsigned off = (unsigned)(d[r] - ubase);
@@ -1038,7 +1064,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 }
 #pragma unroll
                 for (int r = 0; r < W_R; ++r) {
-                    const bool ok = (r << LPT_LOG2) < rem;
+                    const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
                     bool mu = false;
                     if (ok) {
                         const unsigned off = (unsigned)(d[r] - ubase);
@@ -1051,7 +1077,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             // restore the bitmap (every touched word back to 0)
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                if ((r << LPT_LOG2) < rem) {
+                if ((((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem) {
                     const unsigned off = (unsigned)(d[r] - ubase);
                     S.bm[off >> 5] = 0u;
                 }
@@ -1064,7 +1090,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             }
 #pragma unroll
             for (int r = 0; r < W_R; ++r) {
-                const bool ok = (r << LPT_LOG2) < rem;
+                const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
                 const float c = 0.0f + (v[r] * my_idf) * my_qw;
                 const unsigned b = __float_as_uint(c);
                 const bool mu = (multi >> r) & 1u;
@@ -1103,7 +1129,10 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
             const bool fitn = __ballot(lenn > W_R * LPT) == 0ull;  // uniform: every term's run fits W_R steps
             issue(b1, fitn ? lenn : 0, dn, vn);
-            if (__ballot(lenc > W_R * LPT) != 0ull) {
+            if (dbg & 4) {  // timing experiment: loads only (results are wrong)
+#pragma unroll
+                for (int r = 0; r < W_R; ++r) sink += d[r] ^ (int)__float_as_uint(v[r]);
+            } else if (__ballot(lenc > W_R * LPT) != 0ull) {
                 flag_tier2(su);
             } else if (__ballot(lenc > 0) != 0ull) {
                 if (!process(su, lenc, d, v)) flag_tier2(su);
@@ -1125,6 +1154,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         case 5: run(IntC<5>{}); break;
         default: run(IntC<6>{}); break;
     }
+    if ((dbg & 4) && sink == 0x7F123457) cand_count[list] = sink;  // keeps the loads of the timing experiment alive
     if (mcnt > 0) tk = wave_resolve_multi(S, mcnt, k, tk);
     unsigned count = tk.count;
     if (count > (unsigned)k) {

@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _capi
 
+POST_PAD = 16  # SRX_POST_PAD in include/sparse_rx.h
 _TOKEN_RE = re.compile(r"\b\w+\b")
 
 
@@ -146,7 +147,7 @@ class DeviceIndex:
         self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf = term_ptr, post_doc, post_val, tile_skip, idf
         self.n_docs, self.vocab, self.doc_base, self.tile_log2 = int(n_docs), int(vocab), int(doc_base), int(tile_log2)
         self.n_tiles = (self.n_docs + (1 << tile_log2) - 1) >> tile_log2
-        self.nnz = int(post_doc.numel())
+        self.nnz = int(post_doc.numel()) - POST_PAD
         self.val_type = _capi.SRX_VAL_F16 if post_val.dtype == torch.float16 else _capi.SRX_VAL_F32
         d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
                             nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
@@ -231,6 +232,9 @@ class DeviceIndex:
                 post_val = tf.to(torch.float16) if val_dtype == "f16" else tf
             else:
                 raise ValueError(f"unknown mode {mode!r}")
+            # SRX_POST_PAD: the kernels read 4 postings per load and may run past the end of the last list
+            post_doc = torch.cat([post_doc, torch.zeros(POST_PAD, dtype=post_doc.dtype, device=dev)])[:nnz + POST_PAD]
+            post_val = torch.cat([post_val, torch.zeros(POST_PAD, dtype=post_val.dtype, device=dev)])[:nnz + POST_PAD]
             n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
             tile_skip = torch.empty(V * (n_tiles + 1), dtype=torch.int32, device=dev)
             _capi.check(L.srx_build_tile_skip(dev.index or 0, _ptr(term_ptr), _ptr(post_doc), V, n_tiles, tile_log2,
