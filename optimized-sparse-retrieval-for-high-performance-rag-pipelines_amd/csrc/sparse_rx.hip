@@ -1002,6 +1002,8 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             my_idf = ix.idf[term];
             my_qw = q_weight[t0 + tslot];
         }
+        unsigned tau_seen = 0xFFFFFFFFu;  // uniform: tau the screening threshold vthr was derived from
+        float vthr = 0.0f;
         const int32_t *const doc0 = ix.post_doc;
         const VT *const val0 = reinterpret_cast<const VT *>(ix.post_val);
 
@@ -1084,27 +1086,43 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             }
             if (n_multi > (unsigned)W_MCAP) return false;
             if (dbg & 2) return true;
-            if (mcnt + n_multi > (unsigned)W_MCAP) {  // uniform: make room in the pending list
-                tk = wave_resolve_multi(S, mcnt, k, tk);
-                mcnt = 0;
-            }
+            if (n_multi > 0) {  // uniform: park the postings of multi-term docs
+                if (mcnt + n_multi > (unsigned)W_MCAP) {  // make room in the pending list
+                    tk = wave_resolve_multi(S, mcnt, k, tk);
+                    mcnt = 0;
+                }
 #pragma unroll
-            for (int r = 0; r < W_R; ++r) {
-                const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                const float c = 0.0f + (v[r] * my_idf) * my_qw;
-                const unsigned b = __float_as_uint(c);
-                const bool mu = (multi >> r) & 1u;
-                if (!(dbg & 1)) wave_append(S, tk, k, ok && !mu && c > 0.0f && b >= tk.tau, b, d[r]);  // single-term docs
-                if (n_multi > 0) {  // uniform
+                for (int r = 0; r < W_R; ++r) {
+                    const bool mu = (multi >> r) & 1u;
                     const unsigned long long mm = __ballot(mu);
                     if (mm != 0ull) {
                         if (mu) {
                             const unsigned p = mcnt + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
                             S.ml_d[p] = d[r];
-                            S.ml_c[p] = c;
+                            S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
                             S.ml_t[p] = tslot;
                         }
                         mcnt += (unsigned)__popcll(mm);
+                    }
+                }
+            }
+            if (!(dbg & 1)) {
+                // Single-term docs.  Almost no posting can beat tau once the list has warmed up, so a conservative
+                // per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau)
+                // screens them with one compare; the exact fp32 test runs only for survivors.
+                if (tk.tau != tau_seen) {  // uniform, rare
+                    tau_seen = tk.tau;
+                    const float tau_f = __uint_as_float(max(tau_seen, 1u));
+                    vthr = (my_idf > 0.0f && my_qw > 0.0f) ? ((tau_f / my_qw) / my_idf) * 0.99999f : __builtin_inff();
+                }
+#pragma unroll
+                for (int r = 0; r < W_R; ++r) {
+                    const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
+                    const bool pass = ok && !((multi >> r) & 1u) && v[r] >= vthr;
+                    if (__ballot(pass) != 0ull) {  // uniform, rare after warm-up
+                        const float c = 0.0f + (v[r] * my_idf) * my_qw;
+                        const unsigned b = __float_as_uint(c);
+                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r]);
                     }
                 }
             }
