@@ -35,6 +35,23 @@
 
 #define SRX_API extern "C" __attribute__((visibility("default")))
 
+#ifdef SRX_STAMP
+__device__ unsigned long long g_stamp[16];
+#define STAMP(i)                                                                         \
+    do {                                                                                 \
+        unsigned long long t_;                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        st_acc[i] += t_ - st_prev;                                                       \
+        st_prev = t_;                                                                    \
+    } while (0)
+#else
+#define STAMP(i) \
+    do {         \
+    } while (0)
+#endif
+
 namespace {
 
 constexpr int THREADS = 256;
@@ -62,6 +79,7 @@ constexpr int W_R = 12;                     // postings per lane per unit held i
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
 constexpr int W_MCAP = 128;                 // pending postings of multi-term docs (resolved when the list fills)
+constexpr int W_DUPCAP = 8;                 // dup postings per unit resolved by broadcast-compare (more: bitmap re-read)
 constexpr int W_LCAP = 256;                 // lazy top-k list capacity (>= W_KMAX + 64)
 constexpr int W_KMAX = 128;                 // largest k served by tier 1
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
@@ -546,18 +564,14 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
 }
 
 template <typename VT>
-__global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
-                                                               const int32_t *__restrict__ q_term,
-                                                               const float *__restrict__ q_weight, int nq, int k,
-                                                               int n_splits, int super_log2, int n_super, int dbg,
-                                                               const unsigned *__restrict__ ovf, int ovf_words,
-                                                               int lists_per_q, int32_t *__restrict__ cand_doc,
-                                                               float *__restrict__ cand_score,
-                                                               int32_t *__restrict__ cand_count) {
-    __shared__ ScoreShared S;
+__device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const int32_t *__restrict__ q_ptr,
+                            const int32_t *__restrict__ q_term, const float *__restrict__ q_weight, int nq, int k,
+                            int n_splits, int super_log2, int n_super, int dbg, const unsigned *__restrict__ ovf,
+                            int ovf_words, int lists_per_q, int32_t *__restrict__ cand_doc,
+                            float *__restrict__ cand_score, int32_t *__restrict__ cand_count) {
     const int tid = threadIdx.x;
-    const int q = blockIdx.x / n_splits;
-    const int split = blockIdx.x - q * n_splits;
+    const int q = bid / n_splits;
+    const int split = bid - q * n_splits;
     if (q >= nq) return;
     const int64_t list = (int64_t)q * lists_per_q + n_splits + split;  // tier-2 lists follow the tier-1 lists
     const int t0 = q_ptr[q];
@@ -715,6 +729,27 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
     if (tid == 0) cand_count[list] = (int)cnt;
 }
 
+// Tier-2 kernel: a fixed grid of workgroups drains the worklist of (query, split) blocks that tier 1 could not
+// finish (flagged units, > 64 terms, k > 128).  work[0] = number of entries, work[1..] = block ids.
+template <typename VT>
+__global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
+                                                               const int32_t *__restrict__ q_term,
+                                                               const float *__restrict__ q_weight, int nq, int k,
+                                                               int n_splits, int super_log2, int n_super, int dbg,
+                                                               const unsigned *__restrict__ ovf, int ovf_words,
+                                                               int lists_per_q, const int *__restrict__ work,
+                                                               int32_t *__restrict__ cand_doc,
+                                                               float *__restrict__ cand_score,
+                                                               int32_t *__restrict__ cand_count) {
+    __shared__ ScoreShared S;
+    const int n_work = work[0];
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        __syncthreads();  // the previous block's LDS state is dead
+        score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, super_log2, n_super, dbg, ovf,
+                        ovf_words, lists_per_q, cand_doc, cand_score, cand_count);
+    }
+}
+
 // ================================================================================================
 // Tier 1: one wavefront per (query, split).  Wave-synchronous: no s_barrier anywhere; LDS executes one
 // wave's DS instructions in order, wsync() only stops the compiler from reordering across the hand-off.
@@ -736,6 +771,7 @@ struct WaveShared {
     int ml_d[W_MCAP];              // postings of multi-term docs of the current unit (doc, contribution, term slot)
     float ml_c[W_MCAP];
     int ml_t[W_MCAP];
+    int dupdoc[W_DUPCAP];          // doc ids of the current unit's duplicate postings (broadcast to all lanes)
 };
 
 // Exact k-th largest of the wave's keys (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix, 256-bin LDS
@@ -873,7 +909,7 @@ __device__ __forceinline__ void wave_append(WaveShared &S, WaveTopk &tk, int k, 
     const unsigned long long m = __ballot(cand);
     if (m != 0ull) {  // uniform
         if (tk.count > (unsigned)(W_LCAP - 64)) {  // make room for up to 64 more entries
-            tk.tau = wave_list_select(S, tk.count, k);
+            tk.tau = uniu(wave_list_select(S, tk.count, k));
             tk.count = (unsigned)k;
         }
         const bool c2 = cand && bits >= tk.tau;  // tau may just have risen
@@ -955,7 +991,8 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                                                       const float *__restrict__ q_weight, int nq, int k, int n_splits,
                                                       int super_log2, int n_super, int dbg,
                                                       unsigned *__restrict__ ovf, int ovf_words, int lists_per_q,
-                                                      int32_t *__restrict__ cand_doc, float *__restrict__ cand_score,
+                                                      int *__restrict__ work, int32_t *__restrict__ cand_doc,
+                                                      float *__restrict__ cand_score,
                                                       int32_t *__restrict__ cand_count) {
     __shared__ WaveShared S;
     const int lane = threadIdx.x;
@@ -966,7 +1003,10 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int t0 = q_ptr[q];
     const int nt = q_ptr[q + 1] - t0;
     if (nt == 0 || nt > W_MAXT || k > W_KMAX || super_log2 > W_UNIT_LOG2 || (dbg & 8)) {  // tier 2 serves it
-        if (lane == 0) cand_count[list] = 0;
+        if (lane == 0) {
+            cand_count[list] = 0;
+            if (nt > 0) work[1 + atomicAdd(&work[0], 1)] = (int)blockIdx.x;
+        }
         return;
     }
     const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
@@ -980,6 +1020,10 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
     unsigned mcnt = 0;       // wave-uniform: pending multi-term postings in S.ml_*
     int sink = 0;            // debug only
+#ifdef SRX_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
+    bool flagged = false;    // wave-uniform: some unit of this block was handed to tier 2
     int lg = 0;
     while ((1 << lg) < nt) ++lg;
 
@@ -1036,12 +1080,15 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         // score is the single contribution 0 + c, straight from registers.  Postings of docs matched by several
         // terms (rare) are parked in an LDS list and resolved in bulk by wave_resolve_multi (ascending term order).
         // No cross-lane shuffles here: all bookkeeping is ballots on the scalar unit.  false -> tier 2.
-        auto process = [&](int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+        // NR = number of registers that can hold postings in this unit (4 per active load step): the body is
+        // instantiated for 4, 8 and 12 so that idle registers cost nothing.
+        auto process = [&](auto nrc, int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+            constexpr int NR = decltype(nrc)::value;
             const int ubase = su << super_log2;
             const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
-            unsigned old[W_R];
+            unsigned old[NR];
 #pragma unroll
-            for (int r = 0; r < W_R; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
                 old[r] = 0u;
                 if (ok) {
@@ -1051,48 +1098,82 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             }
             unsigned dup = 0;
 #pragma unroll
-            for (int r = 0; r < W_R; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const unsigned off = (unsigned)(d[r] - ubase);
                 if ((old[r] >> (off & 31)) & 1u) dup |= 1u << r;  // old == 0 for idle steps
             }
-            unsigned multi = 0, n_multi = 0;
+            STAMP(2);  // wait for the unit's postings + pass 1 (ds_or_rtn round trip) + dup mask
+            // Which postings belong to docs matched by several terms?  The later postings know (dup); the first posting
+            // of such a doc learns it by comparing its doc id with the (few) dup docs, broadcast through LDS.  With
+            // many dups (dense queries) fall back to pass 2 / pass 3 on the bitmap: dup lanes clear their bit, then
+            // every lane re-reads its bit (cleared = the doc is matched by several terms).
+            unsigned multi = dup, n_multi = 0;
             if (__ballot(dup != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms
+                unsigned nd = 0;  // uniform: number of dup postings
 #pragma unroll
-                for (int r = 0; r < W_R; ++r) {
-                    if ((dup >> r) & 1u) {
-                        const unsigned off = (unsigned)(d[r] - ubase);
-                        atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                for (int r = 0; r < NR; ++r) {
+                    const bool dp = (dup >> r) & 1u;
+                    const unsigned long long mm = __ballot(dp);
+                    if (mm != 0ull) {
+                        const unsigned p = nd + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+                        if (dp && p < (unsigned)W_DUPCAP) S.dupdoc[p] = d[r];
+                        nd += (unsigned)__popcll(mm);
                     }
                 }
+                if (nd <= (unsigned)W_DUPCAP) {
+                    wsync();
+                    for (unsigned e = 0; e < nd; ++e) {  // uniform loop, nd is 1-2 on sparse queries
+                        const int dd = uni(S.dupdoc[e]);
 #pragma unroll
-                for (int r = 0; r < W_R; ++r) {
-                    const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                    bool mu = false;
-                    if (ok) {
-                        const unsigned off = (unsigned)(d[r] - ubase);
-                        mu = !((S.bm[off >> 5] >> (off & 31)) & 1u);
+                        for (int r = 0; r < NR; ++r) {
+                            const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
+                            if (ok && d[r] == dd) multi |= 1u << r;
+                        }
                     }
-                    if (mu) multi |= 1u << r;
-                    n_multi += (unsigned)__popcll(__ballot(mu));
+                    n_multi = 2 * nd;  // upper bound: every dup posting has at most one "first" posting of its own
+                    wsync();
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        if ((dup >> r) & 1u) {
+                            const unsigned off = (unsigned)(d[r] - ubase);
+                            atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
+                        bool mu = false;
+                        if (ok) {
+                            const unsigned off = (unsigned)(d[r] - ubase);
+                            mu = !((S.bm[off >> 5] >> (off & 31)) & 1u);
+                        }
+                        if (mu) multi |= 1u << r;
+                        n_multi += (unsigned)__popcll(__ballot(mu));
+                    }
                 }
             }
+            STAMP(3);  // pass 2 + pass 3
             // restore the bitmap (every touched word back to 0)
 #pragma unroll
-            for (int r = 0; r < W_R; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 if ((((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem) {
                     const unsigned off = (unsigned)(d[r] - ubase);
                     S.bm[off >> 5] = 0u;
                 }
             }
+            STAMP(4);  // restore
             if (n_multi > (unsigned)W_MCAP) return false;
             if (dbg & 2) return true;
             if (n_multi > 0) {  // uniform: park the postings of multi-term docs
                 if (mcnt + n_multi > (unsigned)W_MCAP) {  // make room in the pending list
                     tk = wave_resolve_multi(S, mcnt, k, tk);
+                    tk.count = uniu(tk.count);
+                    tk.tau = uniu(tk.tau);
                     mcnt = 0;
                 }
 #pragma unroll
-                for (int r = 0; r < W_R; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const bool mu = (multi >> r) & 1u;
                     const unsigned long long mm = __ballot(mu);
                     if (mm != 0ull) {
@@ -1106,6 +1187,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     }
                 }
             }
+            STAMP(5);  // parking / resolving multi-term postings
             if (!(dbg & 1)) {
                 // Single-term docs.  Almost no posting can beat tau once the list has warmed up, so a conservative
                 // per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau)
@@ -1116,7 +1198,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     vthr = (my_idf > 0.0f && my_qw > 0.0f) ? ((tau_f / my_qw) / my_idf) * 0.99999f : __builtin_inff();
                 }
 #pragma unroll
-                for (int r = 0; r < W_R; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
                     const bool pass = ok && !((multi >> r) & 1u) && v[r] >= vthr;
                     if (__ballot(pass) != 0ull) {  // uniform, rare after warm-up
@@ -1126,11 +1208,13 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     }
                 }
             }
+            STAMP(6);  // candidate screening + appends (+ selects)
             return true;
         };
 
         auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
             if (lane == 0) atomicOr(&ovf[(int64_t)q * ovf_words + (su >> 5)], 1u << (su & 31));
+            flagged = true;
         };
 
         // ---- software pipeline over units, unrolled by two (register sets A / B alternate): issue the loads of
@@ -1146,14 +1230,23 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
             lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
             const bool fitn = __ballot(lenn > W_R * LPT) == 0ull;  // uniform: every term's run fits W_R steps
+            STAMP(0);  // loop overhead / previous tail
             issue(b1, fitn ? lenn : 0, dn, vn);
+            STAMP(1);  // issue
             if (dbg & 4) {  // timing experiment: loads only (results are wrong)
 #pragma unroll
                 for (int r = 0; r < W_R; ++r) sink += d[r] ^ (int)__float_as_uint(v[r]);
             } else if (__ballot(lenc > W_R * LPT) != 0ull) {
                 flag_tier2(su);
             } else if (__ballot(lenc > 0) != 0ull) {
-                if (!process(su, lenc, d, v)) flag_tier2(su);
+                bool fine;
+                if (__ballot(lenc - 4 * jl > 8 * LPT) != 0ull)  // uniform: the third load step holds postings
+                    fine = process(IntC<12>{}, su, lenc, d, v);
+                else if (__ballot(lenc - 4 * jl > 4 * LPT) != 0ull)
+                    fine = process(IntC<8>{}, su, lenc, d, v);
+                else
+                    fine = process(IntC<4>{}, su, lenc, d, v);
+                if (!fine) flag_tier2(su);
             }
             b1 = b2;
             b2 = b3;
@@ -1184,7 +1277,17 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         cand_doc[o + i] = S.ldoc[i];
         cand_score[o + i] = __uint_as_float(S.lbits[i]);
     }
-    if (lane == 0) cand_count[list] = (int)count;
+    if (lane == 0) {
+        cand_count[list] = (int)count;
+        if (flagged) work[1 + atomicAdd(&work[0], 1)] = (int)blockIdx.x;
+    }
+#ifdef SRX_STAMP
+    STAMP(7);  // epilogue (final resolve / select / list write)
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+        atomicAdd(&g_stamp[8], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1441,7 +1544,7 @@ SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int3
     if (!ix || nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search_workspace_bytes: bad argument%s");
     const Plan p = make_plan(ix, nq, k);
     const int64_t lists = (int64_t)nq * p.lists_per_q;
-    return lists * k * 8 + lists * 4 + (int64_t)nq * p.ovf_words * 4 + 256;
+    return lists * k * 8 + lists * 4 + (int64_t)nq * p.ovf_words * 4 + 4 * (1 + (int64_t)nq * p.n_splits) + 256;
 }
 
 SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
@@ -1463,6 +1566,7 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     float *cand_score = (float *)(cand_doc + lists * k);
     int32_t *cand_count = (int32_t *)(cand_score + lists * k);
     unsigned *ovf = (unsigned *)(cand_count + lists);
+    int *work = (int *)(ovf + (int64_t)nq * p.ovf_words);  // work[0] = count, then block ids
 
     IndexView v;
     v.term_ptr = ix->d.term_ptr;
@@ -1486,28 +1590,30 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
         }
         ev = ix->ev + PROF_EVENTS * (int)(ix->ev_calls % PROF_SLOTS);
     }
-    HIP_TRY(hipMemsetAsync(ovf, 0, (size_t)nq * p.ovf_words * 4, stream));
+    // one memset: list counts (tier-2 lists that never run must read as empty), overflow bitmap, worklist counter
+    HIP_TRY(hipMemsetAsync(cand_count, 0, (size_t)(lists + (int64_t)nq * p.ovf_words + 1) * 4, stream));
     if (prof) HIP_TRY(hipEventRecord(ev[0], stream));
     // tier 1: one wavefront per (query, split)
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
-                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, cand_doc,
-                           cand_score, cand_count);
+                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
+                           cand_doc, cand_score, cand_count);
     else
         hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
-                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, cand_doc,
-                           cand_score, cand_count);
+                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
+                           cand_doc, cand_score, cand_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
-    // tier 2: flagged units, long queries, k > 128
+    // tier 2: flagged units, long queries, k > 128 -- a fixed grid drains the worklist tier 1 filled
+    const unsigned t2_grid = (unsigned)(blocks < 1024 ? blocks : 1024);
     if (ix->d.val_type == SRX_VAL_F32)
-        hipLaunchKernelGGL(srx_score_kernel<float>, dim3((unsigned)blocks), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+        hipLaunchKernelGGL(srx_score_kernel<float>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
                            q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
-                           cand_doc, cand_score, cand_count);
+                           work, cand_doc, cand_score, cand_count);
     else
-        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3((unsigned)blocks), dim3(THREADS), 0, stream, v, q_ptr, q_term,
+        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
                            q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
-                           cand_doc, cand_score, cand_count);
+                           work, cand_doc, cand_score, cand_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
@@ -1622,3 +1728,14 @@ SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const i
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
+
+#ifdef SRX_STAMP
+// Diagnostic build only: cumulative s_memtime ticks per kernel segment (see STAMP in srx_wave_kernel); resets.
+extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
+    return 0;
+}
+#endif
