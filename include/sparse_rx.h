@@ -82,6 +82,11 @@ typedef struct {
     const void *post_val;     /* [nnz + SRX_POST_PAD] f32 or f16 */
     const int32_t *tile_skip; /* [vocab*(n_tiles+1)] */
     const float *idf;         /* [vocab] */
+    const float *term_bound;  /* optional [vocab*4], may be NULL: the K-th largest post_val of each term in this shard for
+                                 K = 1, 10, 100, 1000 (0 where the term has fewer than K postings).  Requires all
+                                 post_val >= 0.  Gives every query an exact lower bound on its k-th best score (a doc's
+                                 score is at least any single contribution when all query idf are >= 0), which the
+                                 kernels use as the initial top-k threshold. */
 } srx_index_desc;
 
 typedef struct srx_index srx_index;

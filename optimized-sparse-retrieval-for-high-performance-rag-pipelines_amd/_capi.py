@@ -36,7 +36,7 @@ class IndexDesc(ctypes.Structure):
                 ("vocab", ctypes.c_int64), ("nnz", ctypes.c_int64), ("doc_base", ctypes.c_int64),
                 ("tile_log2", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("term_ptr", ctypes.c_void_p),
                 ("post_doc", ctypes.c_void_p), ("post_val", ctypes.c_void_p), ("tile_skip", ctypes.c_void_p),
-                ("idf", ctypes.c_void_p)]
+                ("idf", ctypes.c_void_p), ("term_bound", ctypes.c_void_p)]
 
 
 class SearchOpts(ctypes.Structure):

@@ -97,12 +97,16 @@ int fail(int code, const char *fmt, const char *detail = "") {
         if (e_ != hipSuccess) return fail(SRX_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// column of term_bound that is valid for top-k k: the smallest K in {1, 10, 100, 1000} with K >= k (-1: none)
+__host__ __device__ inline int bound_column(int k) { return k <= 1 ? 0 : k <= 10 ? 1 : k <= 100 ? 2 : k <= 1000 ? 3 : -1; }
+
 struct IndexView {
     const int64_t *term_ptr;
     const int32_t *post_doc;
     const void *post_val;
     const int32_t *tile_skip;
     const float *idf;
+    const float *term_bound;  // optional [vocab*4]: K-th largest post_val per term for K = 1, 10, 100, 1000
     int64_t n_docs;
     int64_t vocab;
     int32_t tile_log2;
@@ -594,9 +598,28 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     const int row = ix.n_tiles + 1;
     int *keys = reinterpret_cast<int *>(S.tbl);
 
+    // initial threshold from the index's per-term score bounds (see srx_wave_kernel): exact lower bound on the
+    // k-th best score when every query idf is >= 0
+    unsigned tau0 = 0;
+    {
+        const int col = bound_column(k);
+        unsigned t0b = 0, negf = 0;
+        for (int i = tid; i < nt_all; i += THREADS) {
+            const int term = q_term[t0 + i];
+            const float idf = ix.idf[term], qw = q_weight[t0 + i];
+            if (idf < 0.0f || qw < 0.0f) {
+                negf = 1;
+            } else if (ix.term_bound != nullptr && col >= 0 && idf > 0.0f && qw > 0.0f) {
+                const float b = 0.0f + (ix.term_bound[(int64_t)term * 4 + col] * idf) * qw;
+                t0b = max(t0b, __float_as_uint(b > 0.0f ? b : 0.0f));
+            }
+        }
+        const SumMaxMin r = block_sum_max_min(negf, t0b, 0u, S.tk.red);
+        tau0 = r.sum ? 0u : r.mx;
+    }
     if (tid == 0) {
         S.tk.count = 0;
-        S.tk.tau = 0;
+        S.tk.tau = tau0;
     }
     for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;
     __syncthreads();
@@ -1045,6 +1068,18 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             skip_row = ix.tile_skip + (int64_t)term * row;
             my_idf = ix.idf[term];
             my_qw = q_weight[t0 + tslot];
+        }
+        // Initial threshold: with all query idf >= 0 a doc's score is at least any single contribution, so the K-th
+        // largest contribution of any one term (K >= k, from the index's term_bound table) is an exact lower bound
+        // on this shard's k-th best score.  Candidates below it can be dropped from the very first unit.
+        {
+            const int col = bound_column(k);
+            float bnd = 0.0f;
+            if (ix.term_bound != nullptr && col >= 0 && has_term && my_idf > 0.0f && my_qw > 0.0f)
+                bnd = 0.0f + (ix.term_bound[(int64_t)q_term[t0 + tslot] * 4 + col] * my_idf) * my_qw;
+            const bool neg = has_term && (my_idf < 0.0f || my_qw < 0.0f);
+            const unsigned t0bits = wave_max(__float_as_uint(bnd > 0.0f ? bnd : 0.0f));
+            tk.tau = (__ballot(neg) != 0ull) ? 0u : uniu(t0bits);
         }
         unsigned tau_seen = 0xFFFFFFFFu;  // uniform: tau the screening threshold vthr was derived from
         float vthr = 0.0f;
@@ -1574,6 +1609,7 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     v.post_val = ix->d.post_val;
     v.tile_skip = ix->d.tile_skip;
     v.idf = ix->d.idf;
+    v.term_bound = (ix->opts.reserved & 16) ? nullptr : ix->d.term_bound;  // debug bit 16: ignore the score bounds
     v.n_docs = ix->d.n_docs;
     v.vocab = ix->d.vocab;
     v.tile_log2 = ix->d.tile_log2;

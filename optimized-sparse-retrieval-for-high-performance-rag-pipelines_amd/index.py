@@ -141,10 +141,11 @@ class DeviceIndex:
     keeps pointers."""
 
     def __init__(self, term_ptr, post_doc, post_val, tile_skip, idf, n_docs: int, vocab: int, doc_base: int,
-                 tile_log2: int, device):
+                 tile_log2: int, device, term_bound=None):
         torch = _torch()
         self.device = torch.device(device)
         self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf = term_ptr, post_doc, post_val, tile_skip, idf
+        self.term_bound = term_bound
         self.n_docs, self.vocab, self.doc_base, self.tile_log2 = int(n_docs), int(vocab), int(doc_base), int(tile_log2)
         self.n_tiles = (self.n_docs + (1 << tile_log2) - 1) >> tile_log2
         self.nnz = int(post_doc.numel()) - POST_PAD
@@ -152,7 +153,7 @@ class DeviceIndex:
         d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
                             nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
                             term_ptr=_ptr(term_ptr), post_doc=_ptr(post_doc), post_val=_ptr(post_val),
-                            tile_skip=_ptr(tile_skip), idf=_ptr(idf))
+                            tile_skip=_ptr(tile_skip), idf=_ptr(idf), term_bound=_ptr(term_bound))
         h = ctypes.c_void_p()
         _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
         self._h = h
@@ -163,7 +164,7 @@ class DeviceIndex:
     @classmethod
     def from_csr(cls, indptr, indices, data, idf, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14) -> "DeviceIndex":
+                 tile_log2: int = 14, score_bounds: bool = True) -> "DeviceIndex":
         """Build from a doc-major CSR (host numpy or device torch arrays).
 
         mode "bm25": post_val = impact(tf, len) precomputed in fp32 (retrieval.py:58,70-71), idf as given.
@@ -190,12 +191,12 @@ class DeviceIndex:
             dl = None if doc_lengths is None else to_dev(doc_lengths, torch.float32)
             return cls.from_coo(rows, cols, vals, to_dev(idf, torch.float32), n_docs, doc_lengths=dl, k1=k1, b=b,
                                 avgdl=avgdl, mode=mode, val_dtype=val_dtype, device=dev, doc_base=doc_base,
-                                tile_log2=tile_log2)
+                                tile_log2=tile_log2, score_bounds=score_bounds)
 
     @classmethod
     def from_coo(cls, rows, cols, vals, idf, n_docs: int, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14) -> "DeviceIndex":
+                 tile_log2: int = 14, score_bounds: bool = True) -> "DeviceIndex":
         """Build from device COO triples sorted by (row, col) -- i.e. the CSR's nnz order with explicit rows
         (rows i32 shard-local, cols i32, vals f32).  CSR -> CSC is one stable sort by term, which keeps rows
         ascending inside a term."""
@@ -206,9 +207,10 @@ class DeviceIndex:
             idf_d = idf.to(device=dev, dtype=torch.float32).contiguous()
             V = idf_d.numel()
             nnz = cols.numel()
+            cols_sorted = None
             if nnz > 0:
                 df = torch.bincount(cols, minlength=V)
-                _, perm = torch.sort(cols, stable=True)
+                cols_sorted, perm = torch.sort(cols, stable=True)
                 post_doc = rows[perm].contiguous()
                 tf = vals[perm].contiguous()
                 del perm
@@ -232,6 +234,8 @@ class DeviceIndex:
                 post_val = tf.to(torch.float16) if val_dtype == "f16" else tf
             else:
                 raise ValueError(f"unknown mode {mode!r}")
+            term_bound = cls._term_bounds(torch, cols_sorted, post_val, term_ptr, df, V) if score_bounds else None
+            del cols_sorted
             # SRX_POST_PAD: the kernels read 4 postings per load and may run past the end of the last list
             post_doc = torch.cat([post_doc, torch.zeros(POST_PAD, dtype=post_doc.dtype, device=dev)])[:nnz + POST_PAD]
             post_val = torch.cat([post_val, torch.zeros(POST_PAD, dtype=post_val.dtype, device=dev)])[:nnz + POST_PAD]
@@ -240,7 +244,31 @@ class DeviceIndex:
             _capi.check(L.srx_build_tile_skip(dev.index or 0, _ptr(term_ptr), _ptr(post_doc), V, n_tiles, tile_log2,
                                               _ptr(tile_skip), stream), "srx_build_tile_skip")
             torch.cuda.synchronize(dev)
-        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev)
+        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, term_bound=term_bound)
+
+    BOUND_KS = (1, 10, 100, 1000)
+
+    @staticmethod
+    def _term_bounds(torch, cols_sorted, post_val, term_ptr, df, V):
+        """term_bound[t, j] = the K_j-th largest stored value of term t (0 if it has fewer than K_j postings), or None
+        when some value is negative.  One sort of (term, value descending) keys; exact."""
+        nnz = post_val.numel()
+        if nnz == 0 or cols_sorted is None:
+            return None
+        v32 = post_val.float()
+        if float(v32.min()) < 0.0:
+            return None
+        bits = v32.view(torch.int32).to(torch.int64)  # non-negative floats: integer order == value order
+        key = (cols_sorted.to(torch.int64) << 32) | (0xFFFFFFFF - bits)
+        del bits, v32
+        key = torch.sort(key).values
+        out = torch.zeros((V, len(DeviceIndex.BOUND_KS)), dtype=torch.float32, device=post_val.device)
+        for j, K in enumerate(DeviceIndex.BOUND_KS):
+            has = df >= K
+            pos = (term_ptr[:-1] + (K - 1)).clamp(max=nnz - 1)
+            b = (0xFFFFFFFF - (key[pos] & 0xFFFFFFFF)).to(torch.int32).view(torch.float32)
+            out[:, j] = torch.where(has, b, torch.zeros_like(b))
+        return out.contiguous()
 
     @classmethod
     def from_host_index(cls, hi: HostIndex, k1: float = 1.2, b: float = 0.75, **kw) -> "DeviceIndex":
@@ -297,7 +325,8 @@ class DeviceIndex:
         return {"wave_ms": ms[0], "block_ms": ms[1], "merge_ms": ms[2], "total_ms": ms[3], "calls": n}
 
     def device_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf))
+        ts = [self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf] + ([self.term_bound] if self.term_bound is not None else [])
+        return sum(t.numel() * t.element_size() for t in ts)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
