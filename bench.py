@@ -141,19 +141,12 @@ def main():
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))
-    if dist is not None:
-        g_doc = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-        g_score = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        g_count = torch.empty((world, nq), dtype=torch.int32, device=dev)
+    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of per-shard top-k + merge
+    ix_search = ix.search_device
+    ix.search_device = lambda a, b, c, kk: ix_search(a, b, c, kk, out=out)  # reuse the output tensors every step
 
     def step():
-        ix.search_device(qp, qt, qw, k, out=out)
-        if dist is None:
-            return out
-        dist.all_gather_into_tensor(g_doc, out[0])      # RCCL over xGMI: per-shard top-k, nq*k*4 B per rank each
-        dist.all_gather_into_tensor(g_score, out[1])
-        dist.all_gather_into_tensor(g_count, out[2])
-        return sparse_rx.merge_topk_device(g_doc, g_score, g_count, k, gathered=True)
+        return searcher.search(qp, qt, qw, k)
 
     def barrier():
         if dist is not None:
@@ -176,6 +169,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ix.profile_read()
+
+    pcie_qps = None
+    if dist is None:
+        t = time.perf_counter()
+        for _ in range(3):
+            ix.search(q_ptr, q_term, q_w, k)  # H2D of the query batch + search + D2H of nq*k results
+        pcie_qps = 3 * nq / (time.perf_counter() - t)
+        log(f"[bench] PCIe-inclusive (host query batch in, host results out): {pcie_qps:,.0f} queries/s")
+        ix.profile_read()
 
     # ---- roofline of the dominant kernel (this rank's scoring kernel) --------------------------------------------
     post_bytes = 8 if ix.post_val.dtype == torch.float32 else 6
@@ -211,7 +213,7 @@ def main():
                                f"{nq}-query batch x {w['terms']} terms, k={k}",
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_local * world if world > 1 else nnz_local, "n_queries": nq, "k": k,
                    "sharding": f"doc-range x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
-                   "index_build_s": round(build_s, 2)},
+                   "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>",
                      "kernel_ms": prof["wave_ms"], "tier2_kernel_ms": prof["block_ms"], "merge_kernel_ms": prof["merge_ms"],

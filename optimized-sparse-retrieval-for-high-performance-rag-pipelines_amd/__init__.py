@@ -4,6 +4,8 @@ from . import _capi
 from ._capi import SparseRxError, SparseRxUnavailable, build_library
 from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, merge_topk_device, tokenize
 from .service import RetrievalService
+from .distributed import ShardedSearcher, shard_range, global_df, global_avgdl, bm25_idf_from_df
 
 __all__ = ["RetrievalService", "DeviceIndex", "HostIndex", "build_host_index", "encode_queries", "merge_topk_device",
-           "tokenize", "build_library", "SparseRxError", "SparseRxUnavailable", "_capi"]
+           "tokenize", "build_library", "SparseRxError", "SparseRxUnavailable", "_capi", "ShardedSearcher", "shard_range",
+           "global_df", "global_avgdl", "bm25_idf_from_df"]

@@ -1,0 +1,98 @@
+"""Doc-range sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" = RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference has no distributed code at all; this is the build-side addition of row 8e:
+
+  * documents are independent given GLOBAL statistics, so rank r owns the contiguous rows
+    [r*n/W, (r+1)*n/W) and builds its inverted index over those rows only, but with the corpus-wide
+    df -> idf (retrieval.py:187-189) and avgdl (retrieval.py:190) -- per-shard statistics would change scores;
+  * every rank scores the same query batch against its shard (srx_search returns GLOBAL doc ids: doc_base + row);
+  * ONE exchange step: all-gather of the per-shard top-k blocks [(doc i32, score f32) x nq x k] + counts
+    (nq*k*8 B per rank: 8 MB at 10 k queries, k = 100), then the same exact merge kernel (srx_merge_topk,
+    gathered layout) on every rank -> identical result on all ranks and identical to the 1-GPU result.
+
+The payload is tiny against xGMI (7 links x ~153 GB/s per GPU), so the step is latency-bound: one collective per
+tensor per batch, never per query.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(n_docs: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous doc-id range [a, b) of `rank` (identical rule on every rank)."""
+    return (n_docs * rank) // world, (n_docs * (rank + 1)) // world
+
+
+def global_df(df_local, group=None):
+    """Sum the per-shard document frequencies in place (all-reduce) -> corpus-wide df on every rank."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(df_local, group=group)
+    return df_local
+
+
+def global_avgdl(doc_lengths_local, n_docs_total: int, group=None) -> float:
+    """``float(np.mean(doc_lengths))`` over the WHOLE corpus in global doc order (retrieval.py:190): the shards'
+    length vectors are all-gathered and reduced on the host by NumPy itself, so the value is the reference's."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return float(np.mean(doc_lengths_local.detach().cpu().numpy().astype(np.float32)))
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_docs_total, world, r)[1] - shard_range(n_docs_total, world, r)[0] for r in range(world)]
+    m = max(sizes)  # collectives want equal sizes: pad every shard to the largest, cut the padding after the gather
+    mine = torch.zeros(m, dtype=doc_lengths_local.dtype, device=doc_lengths_local.device)
+    mine[: doc_lengths_local.numel()] = doc_lengths_local
+    out = torch.empty(world * m, dtype=doc_lengths_local.dtype, device=doc_lengths_local.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    parts = [out[r * m: r * m + sizes[r]] for r in range(world)]
+    return float(np.mean(torch.cat(parts).cpu().numpy().astype(np.float32)))
+
+
+def bm25_idf_from_df(df_global, n_docs_total: int) -> np.ndarray:
+    """retrieval.py:187-189 on the corpus-wide df (f64 log, cast to f32)."""
+    df = df_global.detach().cpu().numpy() if hasattr(df_global, "detach") else np.asarray(df_global)
+    return np.log((n_docs_total - df + 0.5) / (df + 0.5)).astype(np.float32)
+
+
+class ShardedSearcher:
+    """search = local search on this rank's shard -> all-gather of the per-shard top-k -> exact merge.
+
+    ``local_search(q_ptr, q_term, q_weight, k) -> (doc i32[nq,k] GLOBAL ids, score f32[nq,k], count i32[nq])`` and
+    ``merge(g_doc [W,nq,k], g_score [W,nq,k], g_count [W,nq], k) -> (doc, score, count)`` are torch-tensor functions
+    on one device.  The product wiring is :meth:`for_device_index` (HIP engine); tests inject CPU callables to
+    exercise the protocol under gloo."""
+
+    def __init__(self, local_search: Callable, merge: Callable, group=None):
+        self.local_search = local_search
+        self.merge = merge
+        self.group = group
+        self._bufs = None
+
+    @classmethod
+    def for_device_index(cls, index, group=None) -> "ShardedSearcher":
+        from .index import merge_topk_device
+        return cls(index.search_device, lambda d, s, c, k: merge_topk_device(d, s, c, k, gathered=True), group)
+
+    def search(self, q_ptr, q_term, q_weight, k: int):
+        import torch
+        import torch.distributed as dist
+        doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return doc, score, count
+        world = dist.get_world_size(self.group)
+        nq = count.shape[0]
+        key = (world, nq, k, doc.device)
+        if self._bufs is None or self._bufs[0] != key:
+            self._bufs = (key, torch.empty((world, nq, k), dtype=doc.dtype, device=doc.device),
+                          torch.empty((world, nq, k), dtype=score.dtype, device=doc.device),
+                          torch.empty((world, nq), dtype=count.dtype, device=doc.device))
+        _, g_doc, g_score, g_count = self._bufs
+        # RCCL over xGMI on the GPU build.  Output = concatenation along dim 0 (the form every backend accepts).
+        dist.all_gather_into_tensor(g_doc.view(world * nq, k), doc.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_score.view(world * nq, k), score.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_count.view(world * nq), count.contiguous(), group=self.group)
+        return self.merge(g_doc, g_score, g_count, k)

@@ -1,0 +1,101 @@
+"""N > 1 path under gloo on the CPU (world_size 2 and 3): shard ranges, corpus-wide statistics by all-reduce /
+all-gather, the all-gather of per-shard top-k and the exact merge.  The per-shard scoring is done by the CPU oracle
+here (tests may use it; the product wiring ShardedSearcher.for_device_index uses the HIP engine and is covered by the
+GPU tests + bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import np_oracle
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _merge_numpy(g_doc, g_score, g_count, k):
+    """Reference merge: union of the per-shard lists, ranked (score desc, doc asc), top k, padded."""
+    W, nq, _ = g_doc.shape
+    out_d = torch.full((nq, k), -1, dtype=torch.int32)
+    out_s = torch.zeros((nq, k), dtype=torch.float32)
+    out_c = torch.zeros((nq,), dtype=torch.int32)
+    for q in range(nq):
+        ds, ss = [], []
+        for w in range(W):
+            c = int(g_count[w, q])
+            ds.append(g_doc[w, q, :c].numpy())
+            ss.append(g_score[w, q, :c].numpy())
+        d = np.concatenate(ds)
+        s = np.concatenate(ss)
+        order = np.lexsort((d, -s.astype(np.float64)))[:k]
+        out_d[q, : len(order)] = torch.from_numpy(d[order].astype(np.int32))
+        out_s[q, : len(order)] = torch.from_numpy(s[order])
+        out_c[q] = len(order)
+    return out_d, out_s, out_c
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sparse_rx
+    from sparse_rx import synth
+    c = synth.zipf_corpus_np(4001, 300, 25, seed=5)  # same corpus on every rank; each uses its own row range
+    q = synth.queries_np(24, c.vocab, 5, seed=6, dist="zipf")
+    k = 20
+    a, b = sparse_rx.shard_range(c.n_docs, world, rank)
+    lo, hi = c.indptr[a], c.indptr[b]
+    sub_ptr = c.indptr[a: b + 1] - lo
+    # corpus-wide statistics from the shards
+    df = torch.from_numpy(np.bincount(c.indices[lo:hi], minlength=c.vocab))
+    sparse_rx.global_df(df)
+    idf = sparse_rx.bm25_idf_from_df(df, c.n_docs)
+    avgdl = sparse_rx.global_avgdl(torch.from_numpy(c.doc_lengths[a:b]), c.n_docs)
+    _, idf_ref, avgdl_ref = synth.corpus_stats(c)
+    assert np.array_equal(idf.view(np.uint32), idf_ref.view(np.uint32)) and avgdl == avgdl_ref
+
+    def local_search(q_ptr, q_term, q_w, kk):
+        d, s, n = oracle.search_batch(sub_ptr, c.indices[lo:hi], c.data[lo:hi], c.doc_lengths[a:b], idf, q_ptr.numpy(),
+                                      q_term.numpy(), q_w.numpy(), kk, 1.2, 0.75, avgdl)
+        d = np.where(d >= 0, d + a, -1).astype(np.int32)  # doc_base
+        return torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(n)
+
+    searcher = sparse_rx.ShardedSearcher(local_search, _merge_numpy)
+    d, s, n = searcher.search(*(torch.from_numpy(x) for x in q), k)
+    ed, es, en = oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf_ref, q[0], q[1], q[2], k, 1.2, 0.75, avgdl_ref)
+    ok = (np.array_equal(n.numpy(), en) and np.array_equal(d.numpy(), ed)
+          and np.array_equal(s.numpy().view(np.uint32), es.view(np.uint32)))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_matches_single_shard(world):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=180)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_shard_range_partitions():
+    import sparse_rx
+    for n in (1, 7, 100, 10_000_000):
+        for w in (1, 2, 3, 8):
+            rs = [sparse_rx.shard_range(n, w, r) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))

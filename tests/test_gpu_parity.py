@@ -251,6 +251,11 @@ def test_merge_topk_matches_single_shard(rx):
         d, s, n = rx.merge_topk_device(in_doc, in_score, in_count, k)
         torch.cuda.synchronize()
         _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"shards={shards}")
+        # the all-gather layout [shards, nq, k]
+        d, s, n = rx.merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]),
+                                       torch.stack([p[2] for p in parts]), k, gathered=True)
+        torch.cuda.synchronize()
+        _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"gathered shards={shards}")
 
 
 def test_impacts_bit_exact(rx):
