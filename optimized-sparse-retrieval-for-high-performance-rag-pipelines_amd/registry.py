@@ -1,0 +1,214 @@
+"""Registry / pipeline adapters and the .npz index cache (row f2).
+
+Mirrors, on the HIP engine, the two other call sites of the reference's hot path:
+  * ``OptimizedBM25Retriever`` + ``RetrieverRegistry``  -- /root/reference/rag_system/core/retriever_registry.py:120-356, 562-599
+  * ``OptimizedRetriever``                              -- /root/reference/rag_system/pipeline/evaluate_rag_pipeline.py:162-479
+    (``bm25*`` types score with ``simd_bm25_score``, every other type with ``simd_tfidf_score`` and
+    idf = log(N/(df+1)), :257-278, :378-399; index cache ``.rag_cache/{method}_index_{hash}.npz``, :189-200, :280-312)
+so that the YAML experiments and ``benchmark_efficiency`` (objects with ``build_index_from_corpus`` + ``search``) run
+unmodified.  The dense / INT8 retriever types of the registry are outside this build's scope and raise.
+"""
+from __future__ import annotations
+
+import hashlib
+import threading
+import time
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, tfidf_idf
+
+_BM25_TYPES = ("bm25", "bm25_retriever", "bm25_custom")
+
+
+class _SparseRetrieverBase:
+    """Shared batched search: cache semantics of the reference call sites, one srx_search per call."""
+
+    mode = "bm25"
+    strip_cache_key = True
+
+    def __init__(self, k1: float, b: float, device: str, tile_log2: int, use_cache: bool = True):
+        self.k1, self.b = k1, b
+        self.device, self.tile_log2 = device, tile_log2
+        self.host: Optional[HostIndex] = None
+        self.dev: Optional[DeviceIndex] = None
+        self.query_cache: Optional[Dict[str, Tuple[np.ndarray, np.ndarray]]] = {} if use_cache else None
+        self.cache_lock = threading.RLock()
+
+    # reference attribute names
+    @property
+    def vocabulary(self):
+        return self.host.vocabulary if self.host else {}
+
+    @property
+    def doc_ids(self):
+        return self.host.doc_ids if self.host else []
+
+    @property
+    def corpus_tf(self):
+        if self.host is None:
+            return None
+        from scipy.sparse import csr_matrix
+        h = self.host
+        return csr_matrix((h.data, h.indices, h.indptr), shape=(h.n_docs, h.vocab_size))
+
+    def _upload(self):
+        if self.dev is not None:
+            self.dev.close()
+        h = self.host
+        if self.mode == "bm25":
+            self.dev = DeviceIndex.from_host_index(h, k1=self.k1, b=self.b, device=self.device, tile_log2=self.tile_log2)
+        else:
+            self.dev = DeviceIndex.from_csr(h.indptr, h.indices, h.data, h.idf, mode="dot", device=self.device,
+                                            tile_log2=self.tile_log2)
+
+    def search(self, queries: Dict[str, str], top_k: int = 10) -> Dict[str, Dict[str, float]]:
+        if self.host is None:
+            raise ValueError("Index not built. Call build_index_from_corpus() first.")
+        results: Dict[str, Dict[str, float]] = {}
+        pending: Dict[str, List[str]] = {}
+        texts, keys = [], []
+        for qid, text in queries.items():
+            if not text:  # retriever_registry.py:237-239
+                results[qid] = {}
+                continue
+            key = f"{text.strip() if self.strip_cache_key else text}:{top_k}"
+            hit = None
+            if self.query_cache is not None:
+                with self.cache_lock:
+                    hit = self.query_cache.get(key)
+            if hit is not None:
+                results[qid] = self._to_dict(*hit)
+                continue
+            results[qid] = {}
+            if key not in pending:
+                pending[key] = []
+                texts.append(text)
+                keys.append(key)
+            pending[key].append(qid)
+        if texts:
+            q_ptr, q_term, q_w = encode_queries(texts, self.host.vocabulary)
+            docs, scores, counts = self.dev.search(q_ptr, q_term, q_w, min(int(top_k), self.host.n_docs))
+            for i, key in enumerate(keys):
+                if q_ptr[i + 1] == q_ptr[i]:
+                    continue
+                c = int(counts[i])
+                entry = (docs[i, :c].astype(np.int64), scores[i, :c].copy())
+                if self.query_cache is not None:
+                    with self.cache_lock:
+                        if len(self.query_cache) < 1000:
+                            self.query_cache[key] = entry
+                d = self._to_dict(*entry)
+                for qid in pending[key]:
+                    results[qid] = dict(d)
+        return results
+
+    def _to_dict(self, idx, sc):
+        ids = self.host.doc_ids
+        return {ids[int(i)]: float(s) for i, s in zip(idx, sc) if s > 0}
+
+    def close(self):
+        if self.dev is not None:
+            self.dev.close()
+            self.dev = None
+
+
+class OptimizedBM25Retriever(_SparseRetrieverBase):
+    """retriever_registry.py:120-356 (``method='tfidf'`` is BM25 with k1=1000, b=0 there, :593-595)."""
+
+    def __init__(self, method: str = "bm25", model: str = None, k1: float = 1.2, b: float = 0.75, device: str = "cuda:0",
+                 tile_log2: int = 14, **kwargs):
+        super().__init__(k1, b, device, tile_log2, use_cache=kwargs.get("cache_queries", True))
+        self.method = method.lower()
+        self.model_name = model
+        self.use_simd = kwargs.get("use_simd", True)  # accepted, meaningless here
+
+    def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
+        if not corpus:
+            raise ValueError("Empty corpus provided")  # retriever_registry.py:155-156
+        self.host = build_host_index(corpus, idf_kind="bm25")
+        self._upload()
+
+
+class OptimizedRetriever(_SparseRetrieverBase):
+    """evaluate_rag_pipeline.py:162-479: config dict + hardware dict; non-BM25 types use the tf-idf dot product."""
+
+    strip_cache_key = False  # its cache key is f"{query_text}:{top_k}" (:340)
+
+    def __init__(self, config: Dict[str, Any], hardware_info: Optional[Dict[str, Any]] = None, device: str = "cuda:0",
+                 tile_log2: int = 14, cache_dir: str = ".rag_cache"):
+        params = config.get("params", {}) or {}
+        hardware_info = hardware_info or {"memory_gb": 8, "cores": 4}
+        super().__init__(params.get("k1", 1.2), params.get("b", 0.75), device, tile_log2,
+                         use_cache=hardware_info.get("memory_gb", 8) > 4)
+        self.config, self.hardware = config, hardware_info
+        self.method = config.get("type", "bm25").lower()
+        self.mode = "bm25" if self.method in ("bm25", "bm25_custom") else "dot"  # :258-261, :378-399
+        self.use_cache = hardware_info.get("memory_gb", 8) > 4
+        self.cache_dir = Path(cache_dir)
+
+    def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
+        corpus_hash = hashlib.md5(str(sorted(corpus.keys())[:1000]).encode()).hexdigest()[:8]  # :189
+        cache_file = self.cache_dir / f"{self.method}_index_{corpus_hash}.npz"
+        if self.use_cache and cache_file.exists():
+            self.host = load_index_npz(cache_file)
+        else:
+            self.host = build_host_index(corpus, idf_kind="bm25" if self.mode == "bm25" else "tfidf")
+            if self.use_cache:
+                self.cache_dir.mkdir(exist_ok=True)
+                save_index_npz(cache_file, self.host)
+        self._upload()
+
+
+def save_index_npz(path, h: HostIndex) -> None:
+    """The reference's cache schema (evaluate_rag_pipeline.py:280-296): same keys and dtypes."""
+    vocab_sorted = sorted(h.vocabulary, key=h.vocabulary.get)
+    np.savez_compressed(path, tf_data=h.data, tf_indices=h.indices, tf_indptr=h.indptr,
+                        tf_shape=np.array((h.n_docs, h.vocab_size), dtype=np.int64), doc_lengths=h.doc_lengths, idf=h.idf,
+                        vocabulary=np.array(vocab_sorted), doc_ids=np.array(h.doc_ids), avgdl=np.float32(h.avgdl))
+
+
+def load_index_npz(path) -> HostIndex:
+    """Reads the schema above with ``allow_pickle=False`` (string arrays are plain ``<U`` arrays)."""
+    z = np.load(path, allow_pickle=False)
+    return HostIndex(indptr=z["tf_indptr"], indices=z["tf_indices"], data=z["tf_data"], doc_lengths=z["doc_lengths"],
+                     idf=z["idf"], avgdl=float(z["avgdl"]), vocabulary={str(t): i for i, t in enumerate(z["vocabulary"])},
+                     doc_ids=[str(d) for d in z["doc_ids"]])
+
+
+class RetrieverRegistry:
+    """retriever_registry.py:562-599."""
+
+    _retrievers: Dict[str, Any] = {}
+
+    @classmethod
+    def register(cls, name: str, retriever_class) -> None:
+        cls._retrievers[name] = retriever_class
+
+    @classmethod
+    def create(cls, config):
+        if isinstance(config, str):
+            method, model, params = config, None, {}
+        else:
+            method = config.get("type", config.get("name"))
+            model = config.get("model")
+            params = config.get("params", {}) or {}
+        if not method:
+            raise ValueError("Retriever name/type not specified")
+        m = method.lower()
+        if m in _BM25_TYPES:
+            return OptimizedBM25Retriever(method=method, model=model, **params)
+        if m == "tfidf":
+            return OptimizedBM25Retriever(method="tfidf", model=model, k1=1000, b=0, **params)  # :593-595
+        if m in ("dpr", "contriever", "splade"):
+            raise NotImplementedError(f"'{method}' maps to the reference's synthetic INT8 embedding retriever "
+                                      "(retriever_registry.py:358-559), which is outside this build's scope")
+        if method in cls._retrievers:
+            return cls._retrievers[method](**params)
+        raise ValueError(f"Unknown retriever method: {method}")
+
+    @classmethod
+    def list_available(cls):
+        return {"optimized_sparse": ["bm25", "bm25_custom", "tfidf"], "registered_custom": list(cls._retrievers.keys())}

@@ -97,3 +97,19 @@ def test_tokenizer_cases():
     assert tk("3.14") == ["3", "14"]
     assert tk("café_1") == ["café_1"]
     assert tk("") == []
+
+
+def test_npz_cache_schema_roundtrip(golden_dir, tmp_path):
+    """save_index_npz writes the reference's .rag_cache schema (evaluate_rag_pipeline.py:280-296) and load_index_npz
+    reads it back without pickle."""
+    j = json.load(open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8"))
+    h = sparse_rx.build_host_index(j["corpus"])
+    p = tmp_path / "bm25_index_test.npz"
+    sparse_rx.save_index_npz(p, h)
+    z = np.load(p, allow_pickle=False)
+    assert set(z.files) == {"tf_data", "tf_indices", "tf_indptr", "tf_shape", "doc_lengths", "idf", "vocabulary", "doc_ids", "avgdl"}
+    assert z["tf_data"].dtype == np.float32 and z["tf_indices"].dtype == np.int32 and z["tf_shape"].dtype == np.int64
+    h2 = sparse_rx.load_index_npz(p)
+    assert h2.doc_ids == h.doc_ids and h2.vocabulary == h.vocabulary
+    assert np.array_equal(h2.data, h.data) and np.array_equal(h2.indices, h.indices) and np.array_equal(h2.indptr, h.indptr)
+    assert np.array_equal(h2.idf.view(np.uint32), h.idf.view(np.uint32)) and h2.avgdl == np.float32(h.avgdl)

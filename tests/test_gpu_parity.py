@@ -300,3 +300,51 @@ def test_larger_properties(rx):
     exp = _oracle_batch(c, idf, avgdl, qs, 100)
     _assert_exact((d100[sample], s100[sample], n100[sample]), exp, "1M sample")
     ix.close()
+
+
+def test_registry_twin_golden(rx, golden_dir, tmp_path):
+    """OptimizedBM25Retriever / RetrieverRegistry / OptimizedRetriever against results the reference's registry twin
+    produced on the same corpus (tests/golden/registry_small.json): bm25, bm25_custom (k1=1.6, b=0.8), tfidf."""
+    with open(os.path.join(golden_dir, "registry_small.json"), encoding="utf-8") as f:
+        reg = json.load(f)
+    with open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8") as f:
+        j = json.load(f)
+    cfgs = {"bm25": {"type": "bm25", "params": {"k1": 1.2, "b": 0.75}},
+            "bm25_msmarco": {"type": "bm25_custom", "params": {"k1": 1.6, "b": 0.8}},
+            "tfidf": {"type": "tfidf"}}
+    for name, cfg in cfgs.items():
+        cfg = dict(cfg)
+        cfg.setdefault("params", {})
+        cfg["params"] = dict(cfg["params"], tile_log2=6)
+        r = rx.RetrieverRegistry.create(cfg)
+        assert (r.k1, r.b) == (reg[name]["k1"], reg[name]["b"])
+        r.build_index_from_corpus(j["corpus"])
+        row = {d: i for i, d in enumerate(r.doc_ids)}
+        for k in ("5", "50"):
+            got = r.search(j["queries"], top_k=int(k))
+            exp = reg[name]["results"][k]
+            assert list(got.keys()) == list(exp.keys())
+            for qid in exp:
+                g, e = got[qid], exp[qid]
+                assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                                    np.array(list(e.values()), np.float32), k=int(k), label=f"{name} k={k} {qid}")
+        r.close()
+    with pytest.raises(NotImplementedError):
+        rx.RetrieverRegistry.create({"type": "dpr"})
+    with pytest.raises(ValueError):
+        rx.RetrieverRegistry.create({"type": "nope"})
+    # pipeline twin: bm25 == the service; .npz cache written then reused
+    pr = rx.OptimizedRetriever({"type": "bm25", "params": {"k1": 1.2, "b": 0.75}}, {"memory_gb": 8, "cores": 4},
+                               tile_log2=6, cache_dir=str(tmp_path / "cache"))
+    pr.build_index_from_corpus(j["corpus"])
+    first = pr.search(j["queries"], top_k=10)
+    assert len(list((tmp_path / "cache").glob("bm25_index_*.npz"))) == 1
+    pr2 = rx.OptimizedRetriever({"type": "bm25"}, {"memory_gb": 8, "cores": 4}, tile_log2=6, cache_dir=str(tmp_path / "cache"))
+    pr2.build_index_from_corpus(j["corpus"])  # loads the cache
+    assert pr2.search(j["queries"], top_k=10) == first
+    exp = j["results"]["10"]
+    for qid in exp:
+        assert list(first[qid].keys()) == list(first[qid].keys())
+        assert np.array_equal(np.array(list(first[qid].values()), np.float32), np.array(list(exp[qid].values()), np.float32)), qid
+    pr.close()
+    pr2.close()
