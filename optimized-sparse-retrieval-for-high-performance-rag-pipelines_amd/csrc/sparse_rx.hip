@@ -1016,7 +1016,9 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                                                       unsigned *__restrict__ ovf, int ovf_words, int lists_per_q,
                                                       int *__restrict__ work, int32_t *__restrict__ cand_doc,
                                                       float *__restrict__ cand_score,
-                                                      int32_t *__restrict__ cand_count) {
+                                                      int32_t *__restrict__ cand_count, int64_t doc_base,
+                                                      int32_t *__restrict__ out_doc, float *__restrict__ out_score,
+                                                      int32_t *__restrict__ out_count) {
     __shared__ WaveShared S;
     const int lane = threadIdx.x;
     const int q = blockIdx.x / n_splits;
@@ -1307,6 +1309,47 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         wave_list_select(S, count, k);
         count = (unsigned)k;
     }
+    if (n_splits == 1 && !flagged && out_doc != nullptr) {
+        // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
+        // the final row, so the merge kernel can skip the query.  Wave-level bitonic sort of 128 keys
+        // (score bits : ~doc, descending) in LDS (the bitmap is no longer needed), two keys per lane, no barrier.
+        unsigned long long *K = reinterpret_cast<unsigned long long *>(S.bm);
+        wsync();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned i = lane + 64 * j;
+            K[i] = i < count ? (((unsigned long long)S.lbits[i] << 32) | (0x7FFFFFFFu - (unsigned)S.ldoc[i])) : 0ull;
+        }
+        wsync();
+        for (unsigned size = 2; size <= 128; size <<= 1) {
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                const unsigned pos = 2 * lane - (lane & (stride - 1));
+                const unsigned long long a = K[pos], b = K[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) {
+                    K[pos] = b;
+                    K[pos + stride] = a;
+                }
+                wsync();
+            }
+        }
+        const int64_t oo = (int64_t)q * k;
+        for (unsigned i = lane; i < (unsigned)k; i += 64) {
+            if (i < count) {
+                const unsigned long long x = K[i];
+                out_doc[oo + i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
+                out_score[oo + i] = __uint_as_float((unsigned)(x >> 32));
+            } else {
+                out_doc[oo + i] = -1;
+                out_score[oo + i] = 0.0f;
+            }
+        }
+        if (lane == 0) {
+            out_count[q] = (int)count;
+            cand_count[list] = -1;  // tells the merge kernel this query is final
+        }
+        return;
+    }
     const int64_t o = list * k;
     for (unsigned i = lane; i < count; i += 64) {
         cand_doc[o + i] = S.ldoc[i];
@@ -1349,6 +1392,7 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
     const int q = blockIdx.x / n_groups;
     const int g = blockIdx.x - q * n_groups;
     if (q >= nq) return;
+    if (!gathered && in_count[(int64_t)q * n_lists] < 0) return;  // tier 1 already wrote this query's final row
     const int l0 = g * lists_per_group;
     const int l1 = min(l0 + lists_per_group, n_lists);
     if (tid == 0) {
@@ -1633,11 +1677,11 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
-                           cand_doc, cand_score, cand_count);
+                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     else
         hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
-                           cand_doc, cand_score, cand_count);
+                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
     // tier 2: flagged units, long queries, k > 128 -- a fixed grid drains the worklist tier 1 filled
