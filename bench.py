@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--tile-log2", type=int, default=14)
     ap.add_argument("--supertile-log2", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
+    ap.add_argument("--unit-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
@@ -133,7 +134,8 @@ def main():
                                         device=dev, doc_base=doc_base, tile_log2=args.tile_log2)
     del rows, cols, tf
     torch.cuda.empty_cache()
-    ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug)
+    ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,
+                unit_tiles=args.unit_tiles)
     build_s = time.perf_counter() - t_build
 
     # ---- query batch, resident in HBM before the timed region --------------------------------------------------

@@ -41,7 +41,7 @@ class IndexDesc(ctypes.Structure):
 
 class SearchOpts(ctypes.Structure):
     _fields_ = [("supertile_log2", ctypes.c_int32), ("target_blocks", ctypes.c_int32), ("profile", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("unit_tiles", ctypes.c_int32)]
 
 
 # every symbol include/sparse_rx.h declares: name -> (restype, argtypes)

@@ -570,7 +570,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
 template <typename VT>
 __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const int32_t *__restrict__ q_ptr,
                             const int32_t *__restrict__ q_term, const float *__restrict__ q_weight, int nq, int k,
-                            int n_splits, int super_log2, int n_super, int dbg, const unsigned *__restrict__ ovf,
+                            int n_splits, int tpu, int n_super, int dbg, const unsigned *__restrict__ ovf,
                             int ovf_words, int lists_per_q, int32_t *__restrict__ cand_doc,
                             float *__restrict__ cand_score, int32_t *__restrict__ cand_count) {
     const int tid = threadIdx.x;
@@ -584,7 +584,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
     // Tier 2 takes the whole query when tier 1 cannot serve it, otherwise only the units tier 1 flagged.
-    const bool all_units = (nt_all > W_MAXT) || (k > W_KMAX) || (super_log2 > W_UNIT_LOG2) || (dbg & 8);
+    const bool all_units = (nt_all > W_MAXT) || (k > W_KMAX) || ((tpu << ix.tile_log2) > (1 << W_UNIT_LOG2)) || (dbg & 8);
     const unsigned *my_ovf = ovf + (int64_t)q * ovf_words;
     bool any = all_units && nt_all > 0;
     if (!all_units && nt_all > 0)
@@ -593,8 +593,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
         if (tid == 0) cand_count[list] = 0;
         return;
     }
-    const int tps_log2 = super_log2 - ix.tile_log2;  // tiles per supertile (log2)
-    const int tps = 1 << tps_log2;
+    const int tps = tpu;  // tiles per unit
     const int row = ix.n_tiles + 1;
     int *keys = reinterpret_cast<int *>(S.tbl);
 
@@ -642,8 +641,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             if (!all_units && !((my_ovf[su >> 5] >> (su & 31)) & 1u)) continue;  // uniform
             int lo = 0, hi = 0;
             if (tid < nt) {
-                lo = skip_row[min(su << tps_log2, ix.n_tiles)];
-                hi = skip_row[min((su + 1) << tps_log2, ix.n_tiles)];
+                lo = skip_row[min(su * tps, ix.n_tiles)];
+                hi = skip_row[min((su + 1) * tps, ix.n_tiles)];
             }
             const int my_len = hi - lo;
             const unsigned P = block_sum((unsigned)my_len, S.tk.red);
@@ -657,7 +656,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             } else if (P > 0) {
                 // ---- overflow: pack this supertile's tiles greedily into units of <= HASH_CAP postings;
                 //      a single tile above that is accumulated densely ----
-                const int ja = su << tps_log2;
+                const int ja = su * tps;
                 const int jb = min(ja + tps, ix.n_tiles);
                 const int nt_tiles = jb - ja;
                 for (int j = tid; j <= nt_tiles; j += THREADS) S.ptile[j] = 0;
@@ -717,8 +716,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     } else {
         // ---- general path (> MAXT query terms): tile by tile, dense accumulators, term passes in
         //      ascending order so the per-doc summation order is unchanged ----
-        const int ja = su_lo << tps_log2;
-        const int jb = min(su_hi << tps_log2, ix.n_tiles);
+        const int ja = su_lo * tps;
+        const int jb = min(su_hi * tps, ix.n_tiles);
         for (int j = ja; j < jb; ++j) {
             const int tile_base = j << ix.tile_log2;
             for (int pass = 0; pass < n_pass; ++pass) {
@@ -758,7 +757,7 @@ template <typename VT>
 __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                                const int32_t *__restrict__ q_term,
                                                                const float *__restrict__ q_weight, int nq, int k,
-                                                               int n_splits, int super_log2, int n_super, int dbg,
+                                                               int n_splits, int tpu, int n_super, int dbg,
                                                                const unsigned *__restrict__ ovf, int ovf_words,
                                                                int lists_per_q, const int *__restrict__ work,
                                                                int32_t *__restrict__ cand_doc,
@@ -768,7 +767,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
     const int n_work = work[0];
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // the previous block's LDS state is dead
-        score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, super_log2, n_super, dbg, ovf,
+        score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, tpu, n_super, dbg, ovf,
                         ovf_words, lists_per_q, cand_doc, cand_score, cand_count);
     }
 }
@@ -1012,7 +1011,7 @@ template <typename VT>
 __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                       const int32_t *__restrict__ q_term,
                                                       const float *__restrict__ q_weight, int nq, int k, int n_splits,
-                                                      int super_log2, int n_super, int dbg,
+                                                      int tpu, int n_super, int dbg,
                                                       unsigned *__restrict__ ovf, int ovf_words, int lists_per_q,
                                                       int *__restrict__ work, int32_t *__restrict__ cand_doc,
                                                       float *__restrict__ cand_score,
@@ -1027,7 +1026,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int64_t list = (int64_t)q * lists_per_q + split;
     const int t0 = q_ptr[q];
     const int nt = q_ptr[q + 1] - t0;
-    if (nt == 0 || nt > W_MAXT || k > W_KMAX || super_log2 > W_UNIT_LOG2 || (dbg & 8)) {  // tier 2 serves it
+    if (nt == 0 || nt > W_MAXT || k > W_KMAX || (tpu << ix.tile_log2) > (1 << W_UNIT_LOG2) || (dbg & 8)) {  // tier 2 serves it
         if (lane == 0) {
             cand_count[list] = 0;
             if (nt > 0) work[1 + atomicAdd(&work[0], 1)] = (int)blockIdx.x;
@@ -1036,7 +1035,6 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     }
     const int su_lo = (int)(((int64_t)n_super * split) / n_splits);
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
-    const int tps_log2 = super_log2 - ix.tile_log2;
     const int row = ix.n_tiles + 1;
 
     for (int i = lane; i < W_BM_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1088,9 +1086,9 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         const int32_t *const doc0 = ix.post_doc;
         const VT *const val0 = reinterpret_cast<const VT *>(ix.post_val);
 
-        // unit boundary j of my term: #postings with doc < (j << super_log2)
+        // unit boundary j of my term: #postings with doc < j * tpu * G
         auto bound = [&](int j) __attribute__((always_inline)) -> int {
-            return has_term ? skip_row[min(j << tps_log2, ix.n_tiles)] : 0;
+            return has_term ? skip_row[min(j * tpu, ix.n_tiles)] : 0;
         };
 
         // Issue the loads of my term's run [lo, lo + len) of the unit.  A lane loads 4 consecutive postings per step
@@ -1121,7 +1119,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         // instantiated for 4, 8 and 12 so that idle registers cost nothing.
         auto process = [&](auto nrc, int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
             constexpr int NR = decltype(nrc)::value;
-            const int ubase = su << super_log2;
+            const int ubase = (su * tpu) << ix.tile_log2;
             const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
             unsigned old[NR];
 #pragma unroll
@@ -1577,6 +1575,7 @@ SRX_API int srx_index_set_opts(srx_index *ix, const srx_search_opts *o) {
     if (!ix || !o) return fail(SRX_ERR_INVALID, "srx_index_set_opts: null argument%s");
     if (o->supertile_log2 != 0 && (o->supertile_log2 < ix->d.tile_log2 || o->supertile_log2 > ix->d.tile_log2 + 6))
         return fail(SRX_ERR_INVALID, "srx_index_set_opts: supertile_log2 must be in [tile_log2, tile_log2+6]%s");
+    if (o->unit_tiles < 0 || o->unit_tiles > MAX_TPS) return fail(SRX_ERR_INVALID, "srx_index_set_opts: unit_tiles must be in [0, 64]%s");
     if (o->target_blocks < 0) return fail(SRX_ERR_INVALID, "srx_index_set_opts: target_blocks < 0%s");
     ix->opts = *o;
     return SRX_OK;
@@ -1584,7 +1583,7 @@ SRX_API int srx_index_set_opts(srx_index *ix, const srx_search_opts *o) {
 
 namespace {
 struct Plan {
-    int super_log2, n_super, n_splits, ovf_words, lists_per_q;
+    int tpu, n_super, n_splits, ovf_words, lists_per_q;  // tpu = tiles per unit
 };
 
 // Supertile (unit) = the doc range one tier-1 unit covers (<= 2^W_UNIT_LOG2 docs, the wave bitmap).  Auto rule: the
@@ -1593,18 +1592,29 @@ struct Plan {
 Plan make_plan(const srx_index *ix, int nq, int k) {
     Plan p;
     const srx_index_desc &d = ix->d;
-    int sl = ix->opts.supertile_log2;
-    if (sl == 0) {
+    const int max_tpu_bitmap = (1 << W_UNIT_LOG2) >> d.tile_log2;  // the tier-1 bitmap covers 65536 docs
+    int tpu;
+    if (ix->opts.unit_tiles > 0) {
+        tpu = ix->opts.unit_tiles;
+    } else if (ix->opts.supertile_log2 != 0) {
+        tpu = 1 << (ix->opts.supertile_log2 - d.tile_log2);
+    } else {
+        // Auto: the largest unit (in tiles) for which the run of an average term inside a unit overflows the registers
+        // of its lane group (8 lanes x W_R postings in the reference case of an 8-term query) with negligible
+        // probability (mean + 5 sigma, Poisson).  Shorter units also keep the per-unit duplicate work (quadratic in
+        // the unit's postings) small.
         const double per_doc_per_term = (double)d.nnz / ((double)d.n_docs * (double)d.vocab);  // E[postings of a term per doc]
-        sl = d.tile_log2;
-        auto fits = [&](int l) {
-            const double mean = per_doc_per_term * (double)(1ll << l);
-            return mean + 3.5 * sqrt(mean) <= 8.0 * W_R;
+        auto fits = [&](int t) {
+            const double mean = per_doc_per_term * (double)t * (double)(1ll << d.tile_log2);
+            return mean + 5.0 * sqrt(mean) <= 8.0 * W_R;
         };
-        while (sl < d.tile_log2 + 6 && sl < W_UNIT_LOG2 && fits(sl + 1)) ++sl;
+        tpu = 1;
+        while (tpu < MAX_TPS && tpu < max_tpu_bitmap && fits(tpu + 1)) ++tpu;
     }
-    p.super_log2 = sl;
-    p.n_super = (int)((d.n_docs + (1ll << sl) - 1) >> sl);
+    if (tpu < 1) tpu = 1;
+    if (tpu > MAX_TPS) tpu = MAX_TPS;
+    p.tpu = tpu;
+    p.n_super = (int)((d.n_tiles + tpu - 1) / tpu);
     const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 8192;  // wave-sized workgroups
     int ns = target / (nq > 0 ? nq : 1);
     if (ns < 1) ns = 1;
@@ -1676,11 +1686,11 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     // tier 1: one wavefront per (query, split)
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
-                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
+                           nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
                            cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     else
         hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
-                           nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
+                           nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
                            cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -1688,11 +1698,11 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     const unsigned t2_grid = (unsigned)(blocks < 1024 ? blocks : 1024);
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_score_kernel<float>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
+                           q_weight, nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
                            work, cand_doc, cand_score, cand_count);
     else
         hipLaunchKernelGGL(srx_score_kernel<__half>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.super_log2, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
+                           q_weight, nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q,
                            work, cand_doc, cand_score, cand_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));

@@ -276,9 +276,10 @@ class DeviceIndex:
                             avgdl=hi.avgdl, **kw)
 
     # -- search ----------------------------------------------------------------------------------------
-    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0) -> None:
+    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0,
+                 unit_tiles: int = 0) -> None:
         self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile),
-                                      reserved=int(debug))
+                                      reserved=int(debug), unit_tiles=int(unit_tiles))
         _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
 
     def workspace_bytes(self, nq: int, k: int) -> int:

@@ -138,6 +138,9 @@ def test_uniform_sparse_hash_path(rx):
     _, idf, avgdl = synth.corpus_stats(c)
     q = synth.queries_np(256, c.vocab, 8, seed=77)
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=12)
+    for ut in (1, 3, 5, 7):  # units of a non-power-of-two number of tiles
+        ix.set_opts(unit_tiles=ut)
+        _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), f"uniform unit_tiles={ut}")
     for sl, tb, dbg in ((0, 0, 0), (12, 0, 0), (16, 1, 0), (14, 100000, 0), (0, 0, 8), (17, 0, 8), (18, 0, 0)):
         ix.set_opts(supertile_log2=sl, target_blocks=tb, debug=dbg)  # debug=8: everything through the tier-2 block kernel
         for k in (100, 10, 128, 129):
