@@ -785,7 +785,6 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct WaveShared {
-    unsigned bm[W_BM_WORDS];       // doc bitmap of the current unit (1 bit per doc)
     int mkeys[W_MSLOTS];           // small hash table for docs matched by more than one query term
     float mvals[W_MSLOTS];
     unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
@@ -1019,6 +1018,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                                                       int32_t *__restrict__ out_doc, float *__restrict__ out_score,
                                                       int32_t *__restrict__ out_count) {
     __shared__ WaveShared S;
+    extern __shared__ __attribute__((aligned(16))) unsigned bm[];  // doc bitmap of the current unit: bm_words words (>= 256)
     const int lane = threadIdx.x;
     const int q = blockIdx.x / n_splits;
     const int split = blockIdx.x - q * n_splits;
@@ -1037,7 +1037,8 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
     const int row = ix.n_tiles + 1;
 
-    for (int i = lane; i < W_BM_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int bm_words = max(256, ((tpu << ix.tile_log2) + 31) >> 5);  // == the launch's dynamic LDS size / 4
+    for (int i = lane; i < bm_words / 4; i += 64) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 old[r] = 0u;
                 if (ok) {
                     const unsigned off = (unsigned)(d[r] - ubase);
-                    old[r] = atomicOr(&S.bm[off >> 5], 1u << (off & 31));
+                    old[r] = atomicOr(&bm[off >> 5], 1u << (off & 31));
                 }
             }
             unsigned dup = 0;
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     for (int r = 0; r < NR; ++r) {
                         if ((dup >> r) & 1u) {
                             const unsigned off = (unsigned)(d[r] - ubase);
-                            atomicAnd(&S.bm[off >> 5], ~(1u << (off & 31)));
+                            atomicAnd(&bm[off >> 5], ~(1u << (off & 31)));
                         }
                     }
 #pragma unroll
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                         bool mu = false;
                         if (ok) {
                             const unsigned off = (unsigned)(d[r] - ubase);
-                            mu = !((S.bm[off >> 5] >> (off & 31)) & 1u);
+                            mu = !((bm[off >> 5] >> (off & 31)) & 1u);
                         }
                         if (mu) multi |= 1u << r;
                         n_multi += (unsigned)__popcll(__ballot(mu));
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             for (int r = 0; r < NR; ++r) {
                 if ((((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem) {
                     const unsigned off = (unsigned)(d[r] - ubase);
-                    S.bm[off >> 5] = 0u;
+                    bm[off >> 5] = 0u;
                 }
             }
             STAMP(4);  // restore
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
         // the final row, so the merge kernel can skip the query.  Wave-level bitonic sort of 128 keys
         // (score bits : ~doc, descending) in LDS (the bitmap is no longer needed), two keys per lane, no barrier.
-        unsigned long long *K = reinterpret_cast<unsigned long long *>(S.bm);
+        unsigned long long *K = reinterpret_cast<unsigned long long *>(bm);
         wsync();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1683,13 +1684,16 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     // one memset: list counts (tier-2 lists that never run must read as empty), overflow bitmap, worklist counter
     HIP_TRY(hipMemsetAsync(cand_count, 0, (size_t)(lists + (int64_t)nq * p.ovf_words + 1) * 4, stream));
     if (prof) HIP_TRY(hipEventRecord(ev[0], stream));
-    // tier 1: one wavefront per (query, split)
+    // tier 1: one wavefront per (query, split); dynamic LDS = the unit's doc bitmap (1 bit per doc, >= 1 KiB, 16-B multiple)
+    int64_t unit_docs = (int64_t)p.tpu << ix->d.tile_log2;
+    if (unit_docs > (1 << W_UNIT_LOG2)) unit_docs = 1 << W_UNIT_LOG2;  // larger units are served by tier 2 anyway
+    const unsigned bm_bytes = (unsigned)(((unit_docs + 31) / 32 < 256 ? 256 : (unit_docs + 31) / 32) * 4 + 15) & ~15u;
     if (ix->d.val_type == SRX_VAL_F32)
-        hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
+        hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), bm_bytes, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
                            cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     else
-        hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, v, q_ptr, q_term, q_weight,
+        hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), bm_bytes, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
                            cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
