@@ -38,6 +38,10 @@ WORKLOADS = {
     # name: n_docs, vocab, nnz/doc, n_queries, terms/query, k, seed
     "c3": dict(n_docs=10_000_000, vocab=100_000, nnz_per_doc=100, n_queries=10_000, terms=8, k=100, seed=20253),
     "c2": dict(n_docs=1_000_000, vocab=50_000, nnz_per_doc=50, n_queries=1_000, terms=8, k=100, seed=20252),
+    # secondary workloads (BASELINE.json configs[3], configs[4]); single-GPU numbers are reported in DESIGN.md only
+    "c4": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20254,
+               kind="splade"),
+    "c5": dict(n_docs=10_000_000, vocab=100_000, nnz_per_doc=100, n_queries=256, terms=8, k=100, seed=20255, kind="zipf"),
 }
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -102,7 +106,9 @@ def main():
     t_build = time.perf_counter()
     rows_l, cols_l, tf_l, dl_l = [], [], [], []
     for ci, c in enumerate(my_chunks):
-        r, cc, tf, dl = synth.uniform_chunk_torch(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev)
+        kind = w.get("kind", "uniform")
+        gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]
+        r, cc, tf, dl = gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev)
         rows_l.append(r + ci * chunk_docs)
         cols_l.append(cc)
         tf_l.append(tf)
@@ -117,8 +123,13 @@ def main():
         dist.all_gather_into_tensor(dl_all, dl)
     else:
         dl_all = dl
+    kind = w.get("kind", "uniform")
     avgdl = float(np.mean(dl_all.cpu().numpy()))  # retrieval.py:190 over the WHOLE corpus
-    idf_np = np.log((n_docs - df.cpu().numpy() + 0.5) / (df.cpu().numpy() + 0.5)).astype(np.float32)  # retrieval.py:189
+    if kind == "splade":  # learned-sparse dot product: no idf, no length normalisation (simd_tfidf_score with idf == 1)
+        idf_np = np.ones(V, dtype=np.float32)
+        avgdl = 1.0
+    else:
+        idf_np = np.log((n_docs - df.cpu().numpy() + 0.5) / (df.cpu().numpy() + 0.5)).astype(np.float32)  # retrieval.py:189
     idf = torch.as_tensor(idf_np, device=dev)
     nnz_local = int(cols.numel())
 
@@ -131,7 +142,9 @@ def main():
         del indptr
 
     ix = sparse_rx.DeviceIndex.from_coo(rows, cols, tf, idf, shard_docs, doc_lengths=dl, k1=1.2, b=0.75, avgdl=avgdl,
-                                        device=dev, doc_base=doc_base, tile_log2=args.tile_log2)
+                                        device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
+                                        mode="dot" if kind == "splade" else "bm25",
+                                        val_dtype="f16" if kind == "splade" else "f32")
     del rows, cols, tf
     torch.cuda.empty_cache()
     ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,
@@ -139,7 +152,12 @@ def main():
     build_s = time.perf_counter() - t_build
 
     # ---- query batch, resident in HBM before the timed region --------------------------------------------------
-    q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1)
+    if kind == "uniform":
+        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1)
+    elif kind == "zipf":
+        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=1.0)
+    else:
+        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=0.7, weights="learned")
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))
@@ -209,7 +227,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f16" if kind == "splade" else "f32",
         "data": "synthetic",
         "config": {"workload": f"{wl_name}: {n_docs} docs x {V} vocab, {w['nnz_per_doc']} nnz/doc, "
                                f"{nq}-query batch x {w['terms']} terms, k={k}",
@@ -217,7 +235,7 @@ def main():
                    "sharding": f"doc-range x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
                    "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>" if kind != "splade" else "srx_score_kernel<__half> (tier 2: k > 128)",
                      "kernel_ms": prof["wave_ms"], "tier2_kernel_ms": prof["block_ms"], "merge_kernel_ms": prof["merge_ms"],
                      "launches_timed": prof["calls"],
                      "algorithmic_bytes_per_launch": alg_bytes},
@@ -232,7 +250,8 @@ def main():
         def run(nsamp):
             qs = (q_ptr[: nsamp + 1] - q_ptr[0], q_term[: q_ptr[nsamp]], q_w[: q_ptr[nsamp]])
             t = time.perf_counter()
-            r = oracle.search_batch(indptr_h, cols_h, tf_h, dl_h, idf_np, qs[0], qs[1], qs[2], k, 1.2, 0.75, avgdl, native=True)
+            r = oracle.search_batch(indptr_h, cols_h, tf_h, dl_h, idf_np, qs[0], qs[1], qs[2], k, 1.2, 0.75, avgdl, native=True,
+                                    mode=oracle.MODE_TFIDF_F32 if kind == "splade" else oracle.MODE_BM25_F32)
             return time.perf_counter() - t, r
         t1, _ = run(1)   # also warms the page cache / thread pool
         t1, _ = run(1)
