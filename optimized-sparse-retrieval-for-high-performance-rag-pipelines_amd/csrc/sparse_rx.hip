@@ -79,7 +79,7 @@ constexpr int W_R = 12;                     // postings per lane per unit held i
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
 constexpr int W_MCAP = 128;                 // pending postings of multi-term docs (resolved when the list fills)
-constexpr int W_DUPCAP = 8;                 // dup postings per unit resolved by broadcast-compare (more: bitmap re-read)
+constexpr int W_DUPCAP = 24;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
 constexpr int W_LCAP = 256;                 // lazy top-k list capacity (>= W_KMAX + 64)
 constexpr int W_KMAX = 128;                 // largest k served by tier 1
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
@@ -789,10 +789,11 @@ struct WaveShared {
     float mvals[W_MSLOTS];
     unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
     int ldoc[W_LCAP];
-    int ml_d[W_MCAP];              // postings of multi-term docs of the current unit (doc, contribution, term slot)
+    int ml_d[W_MCAP];              // pending postings of multi-term docs (doc, contribution, term slot)
     float ml_c[W_MCAP];
     int ml_t[W_MCAP];
-    int dupdoc[W_DUPCAP];          // doc ids of the current unit's duplicate postings (broadcast to all lanes)
+    int dupoff[W_DUPCAP];          // the current unit's duplicate postings (doc offset in the unit), broadcast to all lanes
+    unsigned cnt[4];               // [0] dup postings of the current unit, [1] pending multi-term postings
 };
 
 // Exact k-th largest of the wave's keys (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix, 256-bin LDS
@@ -1037,8 +1038,9 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / n_splits);
     const int row = ix.n_tiles + 1;
 
-    const int bm_words = max(256, ((tpu << ix.tile_log2) + 31) >> 5);  // == the launch's dynamic LDS size / 4
-    for (int i = lane; i < bm_words / 4; i += 64) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int bm_words = max(256, ((tpu << ix.tile_log2) + 31) >> 5);  // the launch's dynamic LDS holds bm_words + 64 words
+    if (lane < 4) S.cnt[lane] = 0;
+    for (int i = lane; i < (bm_words + 64) / 4; i += 64) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
@@ -1110,137 +1112,104 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             }
         };
 
-        // Score one unit from registers.  Pass 1 sets every posting's doc bit (ds_or_rtn): a bit found already set
-        // means another posting of the same doc came earlier.  Pass 2: those lanes clear the bit again, which tells
-        // the earlier posting's lane too.  Pass 3: bit still set = the doc is matched by exactly one term -> its
-        // score is the single contribution 0 + c, straight from registers.  Postings of docs matched by several
-        // terms (rare) are parked in an LDS list and resolved in bulk by wave_resolve_multi (ascending term order).
-        // No cross-lane shuffles here: all bookkeeping is ballots on the scalar unit.  false -> tier 2.
-        // NR = number of registers that can hold postings in this unit (4 per active load step): the body is
-        // instantiated for 4, 8 and 12 so that idle registers cost nothing.
-        auto process = [&](auto nrc, int su, int len, const int (&d)[W_R], const float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+        // Score one unit from registers.  Idle lanes are made harmless once (private dummy bitmap word with a distinct
+        // bit per register, value 0) and d[] becomes the doc offset inside the unit, so every pass runs unpredicated.
+        // Pass 1 sets every posting's doc bit (ds_or_rtn).  A bit found already set means an earlier posting matched
+        // the same doc: that (rare) lane parks its posting in the pending list, publishes the doc through LDS and
+        // blanks its value.  The first posting of such a doc finds itself by comparing against the few published
+        // docs and parks too.  Everything still non-blank is a single-term doc whose score is 0 + c, screened with
+        // one compare against a conservative per-lane threshold.  Parked postings are summed by wave_resolve_multi in
+        // ascending term order (exact).  Slots in the LDS lists come from LDS counters inside the rare exec-masked
+        // blocks, so the common path carries no per-lane masks.  false -> the unit goes to tier 2 (nothing emitted).
+        auto process = [&](auto nrc, int su, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> bool {
             constexpr int NR = decltype(nrc)::value;
             const int ubase = (su * tpu) << ix.tile_log2;
             const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
+            const int dummy = (bm_words + lane) << 5;
+            if (mcnt > (unsigned)(W_MCAP - 2 * W_DUPCAP)) {  // uniform: room for this unit's multi-term postings
+                tk = wave_resolve_multi(S, mcnt, k, tk);
+                tk.count = uniu(tk.count);
+                tk.tau = uniu(tk.tau);
+                mcnt = 0;
+                if (lane == 0) S.cnt[1] = 0;
+            }
             unsigned old[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                old[r] = 0u;
-                if (ok) {
-                    const unsigned off = (unsigned)(d[r] - ubase);
-                    old[r] = atomicOr(&bm[off >> 5], 1u << (off & 31));
-                }
+                d[r] = ok ? d[r] - ubase : dummy + r;
+                v[r] = ok ? v[r] : 0.0f;
+                old[r] = atomicOr(&bm[(unsigned)d[r] >> 5], 1u << (d[r] & 31));
             }
-            unsigned dup = 0;
+            STAMP(2);  // wait for the unit's postings + pass 1
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const unsigned off = (unsigned)(d[r] - ubase);
-                if ((old[r] >> (off & 31)) & 1u) dup |= 1u << r;  // old == 0 for idle steps
-            }
-            STAMP(2);  // wait for the unit's postings + pass 1 (ds_or_rtn round trip) + dup mask
-            // Which postings belong to docs matched by several terms?  The later postings know (dup); the first posting
-            // of such a doc learns it by comparing its doc id with the (few) dup docs, broadcast through LDS.  With
-            // many dups (dense queries) fall back to pass 2 / pass 3 on the bitmap: dup lanes clear their bit, then
-            // every lane re-reads its bit (cleared = the doc is matched by several terms).
-            unsigned multi = dup, n_multi = 0;
-            if (__ballot(dup != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms
-                unsigned nd = 0;  // uniform: number of dup postings
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const bool dp = (dup >> r) & 1u;
-                    const unsigned long long mm = __ballot(dp);
-                    if (mm != 0ull) {
-                        const unsigned p = nd + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
-                        if (dp && p < (unsigned)W_DUPCAP) S.dupdoc[p] = d[r];
-                        nd += (unsigned)__popcll(mm);
+                if ((old[r] >> (d[r] & 31)) & 1u) {  // rare: an earlier posting of this unit has the same doc
+                    const unsigned e = atomicAdd(&S.cnt[0], 1u);
+                    if (e < (unsigned)W_DUPCAP) S.dupoff[e] = d[r];
+                    const unsigned p = atomicAdd(&S.cnt[1], 1u);
+                    if (p < (unsigned)W_MCAP) {
+                        S.ml_d[p] = d[r] + ubase;
+                        S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
+                        S.ml_t[p] = tslot;
                     }
+                    v[r] = 0.0f;
                 }
+            }
+            wsync();
+            const unsigned nd = uniu(S.cnt[0]);
+            bool dense = false;
+            if (nd != 0) {  // uniform
                 if (nd <= (unsigned)W_DUPCAP) {
-                    wsync();
-                    for (unsigned e = 0; e < nd; ++e) {  // uniform loop, nd is 1-2 on sparse queries
-                        const int dd = uni(S.dupdoc[e]);
+                    for (unsigned e = 0; e < nd; ++e) {  // uniform loop, about one entry per unit on sparse queries
+                        const int dd = uni(S.dupoff[e]);
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
-                            const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                            if (ok && d[r] == dd) multi |= 1u << r;
+                            if (d[r] == dd && v[r] != 0.0f) {  // rare: the first posting of a multi-term doc
+                                const unsigned p = atomicAdd(&S.cnt[1], 1u);
+                                S.ml_d[p] = d[r] + ubase;  // p < W_MCAP: room for 2 * W_DUPCAP was made above
+                                S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
+                                S.ml_t[p] = tslot;
+                                v[r] = 0.0f;
+                            }
                         }
                     }
-                    n_multi = 2 * nd;  // upper bound: every dup posting has at most one "first" posting of its own
-                    wsync();
                 } else {
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        if ((dup >> r) & 1u) {
-                            const unsigned off = (unsigned)(d[r] - ubase);
-                            atomicAnd(&bm[off >> 5], ~(1u << (off & 31)));
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                        bool mu = false;
-                        if (ok) {
-                            const unsigned off = (unsigned)(d[r] - ubase);
-                            mu = !((bm[off >> 5] >> (off & 31)) & 1u);
-                        }
-                        if (mu) multi |= 1u << r;
-                        n_multi += (unsigned)__popcll(__ballot(mu));
-                    }
+                    dense = true;  // too many multi-term docs for this path: drop what was parked, tier 2 takes the unit
                 }
-            }
-            STAMP(3);  // pass 2 + pass 3
-            // restore the bitmap (every touched word back to 0)
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if ((((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem) {
-                    const unsigned off = (unsigned)(d[r] - ubase);
-                    bm[off >> 5] = 0u;
+                wsync();
+                if (lane == 0) {
+                    S.cnt[0] = 0;
+                    if (dense) S.cnt[1] = mcnt;
                 }
+                wsync();
+                mcnt = uniu(S.cnt[1]);
             }
+            STAMP(3);  // duplicate resolution
+#pragma unroll
+            for (int r = 0; r < NR; ++r) bm[(unsigned)d[r] >> 5] = 0u;  // restore the bitmap
             STAMP(4);  // restore
-            if (n_multi > (unsigned)W_MCAP) return false;
+            if (dense) return false;
             if (dbg & 2) return true;
-            if (n_multi > 0) {  // uniform: park the postings of multi-term docs
-                if (mcnt + n_multi > (unsigned)W_MCAP) {  // make room in the pending list
-                    tk = wave_resolve_multi(S, mcnt, k, tk);
-                    tk.count = uniu(tk.count);
-                    tk.tau = uniu(tk.tau);
-                    mcnt = 0;
-                }
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const bool mu = (multi >> r) & 1u;
-                    const unsigned long long mm = __ballot(mu);
-                    if (mm != 0ull) {
-                        if (mu) {
-                            const unsigned p = mcnt + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
-                            S.ml_d[p] = d[r];
-                            S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
-                            S.ml_t[p] = tslot;
-                        }
-                        mcnt += (unsigned)__popcll(mm);
-                    }
-                }
-            }
-            STAMP(5);  // parking / resolving multi-term postings
+            STAMP(5);
             if (!(dbg & 1)) {
                 // Single-term docs.  Almost no posting can beat tau once the list has warmed up, so a conservative
-                // per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau)
-                // screens them with one compare; the exact fp32 test runs only for survivors.
+                // per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau,
+                // and > 0 so that blanked registers never pass) screens them with one compare; the exact fp32 test
+                // runs only for survivors.
                 if (tk.tau != tau_seen) {  // uniform, rare
                     tau_seen = tk.tau;
                     const float tau_f = __uint_as_float(max(tau_seen, 1u));
-                    vthr = (my_idf > 0.0f && my_qw > 0.0f) ? ((tau_f / my_qw) / my_idf) * 0.99999f : __builtin_inff();
+                    vthr = (my_idf > 0.0f && my_qw > 0.0f) ? fmaxf(((tau_f / my_qw) / my_idf) * 0.99999f, __uint_as_float(1u))
+                                                         : __builtin_inff();
                 }
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const bool ok = (((r >> 2) << (LPT_LOG2 + 2)) + (r & 3)) < rem;
-                    const bool pass = ok && !((multi >> r) & 1u) && v[r] >= vthr;
+                    const bool pass = v[r] >= vthr;
                     if (__ballot(pass) != 0ull) {  // uniform, rare after warm-up
                         const float c = 0.0f + (v[r] * my_idf) * my_qw;
                         const unsigned b = __float_as_uint(c);
-                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r]);
+                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r] + ubase);
                     }
                 }
             }
@@ -1261,7 +1230,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         int lenA = (su_lo < su_hi) ? b1 - b0 : 0, lenB = 0;
         issue(b0, (__ballot(lenA > W_R * LPT) == 0ull) ? lenA : 0, dA, vA);
         // one stage: unit su is in (lenc, d, v); unit su+1 goes to (lenn, dn, vn)
-        auto stage = [&](int su, int lenc, const int (&d)[W_R], const float (&v)[W_R], int &lenn, int (&dn)[W_R],
+        auto stage = [&](int su, int lenc, int (&d)[W_R], float (&v)[W_R], int &lenn, int (&dn)[W_R],
                          float (&vn)[W_R]) __attribute__((always_inline)) {
             const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
             lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
@@ -1687,7 +1656,7 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     // tier 1: one wavefront per (query, split); dynamic LDS = the unit's doc bitmap (1 bit per doc, >= 1 KiB, 16-B multiple)
     int64_t unit_docs = (int64_t)p.tpu << ix->d.tile_log2;
     if (unit_docs > (1 << W_UNIT_LOG2)) unit_docs = 1 << W_UNIT_LOG2;  // larger units are served by tier 2 anyway
-    const unsigned bm_bytes = (unsigned)(((unit_docs + 31) / 32 < 256 ? 256 : (unit_docs + 31) / 32) * 4 + 15) & ~15u;
+    const unsigned bm_bytes = ((unsigned)(((unit_docs + 31) / 32 < 256 ? 256 : (unit_docs + 31) / 32) * 4 + 15) & ~15u) + 256u;  // + 64 dummy words
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), bm_bytes, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
