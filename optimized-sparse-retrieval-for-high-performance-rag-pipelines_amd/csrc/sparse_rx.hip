@@ -1277,6 +1277,13 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         wave_list_select(S, count, k);
         count = (unsigned)k;
     }
+#ifdef SRX_STAMP
+    STAMP(7);  // epilogue (final resolve / select)
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+        atomicAdd(&g_stamp[8], 1ull);
+    }
+#endif
     if (n_splits == 1 && !flagged && out_doc != nullptr) {
         // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
         // the final row, so the merge kernel can skip the query.  Wave-level bitonic sort of 128 keys
@@ -1327,13 +1334,6 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         cand_count[list] = (int)count;
         if (flagged) work[1 + atomicAdd(&work[0], 1)] = (int)blockIdx.x;
     }
-#ifdef SRX_STAMP
-    STAMP(7);  // epilogue (final resolve / select / list write)
-    if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
-        atomicAdd(&g_stamp[8], 1ull);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1585,7 +1585,7 @@ Plan make_plan(const srx_index *ix, int nq, int k) {
     if (tpu > MAX_TPS) tpu = MAX_TPS;
     p.tpu = tpu;
     p.n_super = (int)((d.n_tiles + tpu - 1) / tpu);
-    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 8192;  // wave-sized workgroups
+    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 4096;  // wave-sized workgroups (256 CUs x 12 waves resident; measured best on 1 k-query batches)
     int ns = target / (nq > 0 ? nq : 1);
     if (ns < 1) ns = 1;
     if (ns > p.n_super) ns = p.n_super;
