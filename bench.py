@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: run the N > 1 code path (RCCL all-gather + packed merge) with world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,11 +78,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -161,7 +164,8 @@ def main():
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))
-    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of per-shard top-k + merge
+    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + ONE RCCL all-gather of the packed per-shard top-k + merge
+    searcher.force_exchange = args.force_dist
     ix_search = ix.search_device
     ix.search_device = lambda a, b, c, kk: ix_search(a, b, c, kk, out=out)  # reuse the output tensors every step
 
@@ -232,7 +236,7 @@ def main():
         "config": {"workload": f"{wl_name}: {n_docs} docs x {V} vocab, {w['nnz_per_doc']} nnz/doc, "
                                f"{nq}-query batch x {w['terms']} terms, k={k}",
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_local * world if world > 1 else nnz_local, "n_queries": nq, "k": k,
-                   "sharding": f"doc-range x{world}" + (" + RCCL all-gather of per-shard top-k" if world > 1 else ""),
+                   "sharding": f"doc-range x{world}" + (" + one RCCL all-gather of packed per-shard top-k" if (world > 1 or args.force_dist) else ""),
                    "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>" if kind != "splade" else "srx_score_kernel<__half> (tier 2: k > 128)",

@@ -139,6 +139,15 @@ int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *in_score,
                    int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
                    int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream);
 
+/*
+ * Same merge over PACKED rows, the single-buffer form of the multi-GPU exchange: packed is
+ * [n_lists][nq][2k+1] int32 with row = k doc ids, k fp32 score bit patterns, 1 count -- each rank packs its
+ * srx_search outputs into [nq][2k+1], ONE all-gather produces this buffer, and the merge reads it in place.
+ */
+int srx_merge_topk_packed(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
+                          int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                          int64_t workspace_bytes, void *stream);
+
 /* ---- device-side index construction helpers ------------------------------------------------------ */
 
 /* impact[p] = (tf[p]*(k1+1)) / (tf[p] + k1*(1-b + b*doc_len[post_doc[p]]/avgdl)), fp32, the reference's

@@ -1352,7 +1352,8 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
                                                             const float *__restrict__ in_score,
                                                             const int32_t *__restrict__ in_count, int nq, int n_lists,
                                                             int k, int lists_per_group, int n_groups, int final_pass,
-                                                            int gathered, int64_t doc_base, int32_t *__restrict__ out_doc,
+                                                            int gathered, int64_t row_stride, int64_t cnt_stride,
+                                                            int64_t doc_base, int32_t *__restrict__ out_doc,
                                                             float *__restrict__ out_score,
                                                             int32_t *__restrict__ out_count) {
     __shared__ MergeShared M;
@@ -1360,7 +1361,7 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
     const int q = blockIdx.x / n_groups;
     const int g = blockIdx.x - q * n_groups;
     if (q >= nq) return;
-    if (!gathered && in_count[(int64_t)q * n_lists] < 0) return;  // tier 1 already wrote this query's final row
+    if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
     const int l0 = g * lists_per_group;
     const int l1 = min(l0 + lists_per_group, n_lists);
     if (tid == 0) {
@@ -1381,9 +1382,9 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
             const int l = l0 + c / k, r = c - (c / k) * k;
             // layout 0: [nq][n_lists][k] (+ counts [nq][n_lists]); gathered: [n_lists][nq][k] (+ [n_lists][nq])
             const int64_t li = gathered ? ((int64_t)l * nq + q) : ((int64_t)q * n_lists + l);
-            const int cnt = in_count[li];
+            const int cnt = in_count[li * cnt_stride];
             if (r < cnt) {
-                const int64_t a = li * k + r;
+                const int64_t a = li * row_stride + r;  // row_stride = k for plain lists, 2k+1 for packed rows
                 const float s = in_score[a];
                 if (s > 0.0f) {
                     ubits[n] = __float_as_uint(s);
@@ -1680,7 +1681,7 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
-                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, ix->d.doc_base, out_doc, out_score, out_count);
+                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(ev[3], stream));
@@ -1723,11 +1724,11 @@ SRX_API int64_t srx_merge_workspace_bytes(int32_t nq, int32_t n_lists, int32_t k
     return 2 * ((int64_t)nq * g * k * 8 + (int64_t)nq * g * 4 + 256);
 }
 
-SRX_API int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count,
-                           int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
-                           int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+namespace {
+int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count, int32_t nq,
+               int32_t n_lists, int32_t k, int lay, int64_t row_stride, int64_t cnt_stride, int32_t *out_doc,
+               float *out_score, int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
     if (nq < 0 || n_lists <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_merge_topk: bad argument%s");
-    int lay = gathered ? 1 : 0;
     if (nq == 0) return SRX_OK;
     if (!in_doc || !in_score || !in_count || !out_doc || !out_score || !out_count)
         return fail(SRX_ERR_INVALID, "srx_merge_topk: null pointer%s");
@@ -1736,32 +1737,52 @@ SRX_API int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *i
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_v;
     const int fan = (MERGE_NPT * THREADS) / k;
-    const int32_t *cd = in_doc;
-    const float *cs = in_score;
-    const int32_t *cc = in_count;
+    const int32_t *cur_doc = in_doc;
+    const float *cur_score = in_score;
+    const int32_t *cur_count = in_count;
     int lists = n_lists;
     int level = 0;
     const int64_t half = need / 2;
-    while (lists > fan) {
+    while (lists > fan) {  // tree levels: groups of `fan` lists -> one unordered list each (plain layout)
         const int groups = (lists + fan - 1) / fan;
         char *buf = (char *)workspace + (level & 1) * half;
         int32_t *od = (int32_t *)buf;
         float *os = (float *)(od + (int64_t)nq * groups * k);
         int32_t *oc = (int32_t *)(os + (int64_t)nq * groups * k);
-        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cd, cs, cc,
-                           nq, lists, k, fan, groups, 0, lay, (int64_t)0, od, os, oc);
-        lay = 0;
+        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cur_doc,
+                           cur_score, cur_count, nq, lists, k, fan, groups, 0, lay, row_stride, cnt_stride, (int64_t)0, od, os,
+                           oc);
         HIP_TRY(hipGetLastError());
-        cd = od;
-        cs = os;
-        cc = oc;
+        lay = 0;
+        row_stride = k;
+        cnt_stride = 1;
+        cur_doc = od;
+        cur_score = os;
+        cur_count = oc;
         lists = groups;
         ++level;
     }
-    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cd, cs, cc, nq, lists, k, lists, 1,
-                       1, lay, (int64_t)0, out_doc, out_score, out_count);
+    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
+                       lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count);
     HIP_TRY(hipGetLastError());
     return SRX_OK;
+}
+}  // namespace
+
+SRX_API int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count,
+                           int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
+                           int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    return merge_impl(device, in_doc, in_score, in_count, nq, n_lists, k, gathered ? 1 : 0, (int64_t)k, (int64_t)1, out_doc,
+                      out_score, out_count, workspace, workspace_bytes, stream_v);
+}
+
+SRX_API int srx_merge_topk_packed(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
+                                  int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                                  int64_t workspace_bytes, void *stream_v) {
+    if (!packed || k <= 0) return fail(SRX_ERR_INVALID, "srx_merge_topk_packed: bad argument%s");
+    const int64_t row = 2 * (int64_t)k + 1;  // [k doc ids][k score bit patterns][count]
+    return merge_impl(device, packed, reinterpret_cast<const float *>(packed + k), packed + 2 * k, nq, n_lists, k, 1, row, row,
+                      out_doc, out_score, out_count, workspace, workspace_bytes, stream_v);
 }
 
 SRX_API int srx_build_impacts(int32_t device, const float *tf, const int32_t *post_doc, const float *doc_len,

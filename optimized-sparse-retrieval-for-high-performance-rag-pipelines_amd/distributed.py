@@ -59,40 +59,38 @@ def bm25_idf_from_df(df_global, n_docs_total: int) -> np.ndarray:
 
 
 class ShardedSearcher:
-    """search = local search on this rank's shard -> all-gather of the per-shard top-k -> exact merge.
+    """search = local search on this rank's shard -> ONE all-gather of the packed per-shard top-k -> exact merge.
 
-    ``local_search(q_ptr, q_term, q_weight, k) -> (doc i32[nq,k] GLOBAL ids, score f32[nq,k], count i32[nq])`` and
-    ``merge(g_doc [W,nq,k], g_score [W,nq,k], g_count [W,nq], k) -> (doc, score, count)`` are torch-tensor functions
-    on one device.  The product wiring is :meth:`for_device_index` (HIP engine); tests inject CPU callables to
-    exercise the protocol under gloo."""
+    ``local_search(q_ptr, q_term, q_weight, k) -> (doc i32[nq,k] GLOBAL ids, score f32[nq,k], count i32[nq])``,
+    ``pack(doc, score, count) -> i32[nq, 2k+1]`` and ``merge(packed i32[W, nq, 2k+1], k) -> (doc, score, count)`` are
+    torch-tensor functions on one device.  The product wiring is :meth:`for_device_index` (HIP engine:
+    ``srx_search`` + ``srx_merge_topk_packed``); tests inject CPU callables to exercise the protocol under gloo."""
 
-    def __init__(self, local_search: Callable, merge: Callable, group=None):
+    def __init__(self, local_search: Callable, pack: Callable, merge: Callable, group=None):
         self.local_search = local_search
+        self.pack = pack
         self.merge = merge
         self.group = group
-        self._bufs = None
+        self._buf = None
 
     @classmethod
     def for_device_index(cls, index, group=None) -> "ShardedSearcher":
-        from .index import merge_topk_device
-        return cls(index.search_device, lambda d, s, c, k: merge_topk_device(d, s, c, k, gathered=True), group)
+        from .index import merge_topk_packed_device, pack_results
+        return cls(index.search_device, pack_results, merge_topk_packed_device, group)
 
     def search(self, q_ptr, q_term, q_weight, k: int):
         import torch
         import torch.distributed as dist
         doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1) and not getattr(self, "force_exchange", False):
             return doc, score, count
         world = dist.get_world_size(self.group)
         nq = count.shape[0]
-        key = (world, nq, k, doc.device)
-        if self._bufs is None or self._bufs[0] != key:
-            self._bufs = (key, torch.empty((world, nq, k), dtype=doc.dtype, device=doc.device),
-                          torch.empty((world, nq, k), dtype=score.dtype, device=doc.device),
-                          torch.empty((world, nq), dtype=count.dtype, device=doc.device))
-        _, g_doc, g_score, g_count = self._bufs
-        # RCCL over xGMI on the GPU build.  Output = concatenation along dim 0 (the form every backend accepts).
-        dist.all_gather_into_tensor(g_doc.view(world * nq, k), doc.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_score.view(world * nq, k), score.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_count.view(world * nq), count.contiguous(), group=self.group)
-        return self.merge(g_doc, g_score, g_count, k)
+        mine = self.pack(doc, score, count)  # [nq, 2k+1] i32: nq*(8k+4) bytes per rank
+        key = (world, nq, k, mine.device)
+        if self._buf is None or self._buf[0] != key:
+            self._buf = (key, torch.empty((world, nq, 2 * k + 1), dtype=torch.int32, device=mine.device))
+        g = self._buf[1]
+        # RCCL over xGMI on the GPU build; output = concatenation along dim 0 (the form every backend accepts)
+        dist.all_gather_into_tensor(g.view(world * nq, 2 * k + 1), mine, group=self.group)
+        return self.merge(g, k)

@@ -361,3 +361,33 @@ def merge_topk_device(in_doc, in_score, in_count, k: int, gathered: bool = False
                               _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream_ptr(torch, dev))
         _capi.check(rc, "srx_merge_topk")
     return out
+
+
+def pack_results(doc, score, count):
+    """(doc i32[nq,k], score f32[nq,k], count i32[nq]) -> one i32 tensor [nq, 2k+1] (row = docs, score bits, count)."""
+    torch = _torch()
+    nq, k = doc.shape
+    out = torch.empty((nq, 2 * k + 1), dtype=torch.int32, device=doc.device)
+    out[:, :k] = doc
+    out[:, k:2 * k] = score.view(torch.int32)
+    out[:, 2 * k] = count
+    return out
+
+
+def merge_topk_packed_device(packed, k: int):
+    """``srx_merge_topk_packed`` on a device tensor [n_lists, nq, 2k+1] (the all-gather of pack_results rows)."""
+    torch = _torch()
+    n_lists, nq, row = packed.shape
+    assert row == 2 * k + 1 and packed.dtype == torch.int32
+    dev = packed.device
+    L = _capi.lib()
+    with torch.cuda.device(dev):
+        out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+               torch.empty((nq,), dtype=torch.int32, device=dev))
+        need = _capi.check(L.srx_merge_workspace_bytes(nq, n_lists, k), "srx_merge_workspace_bytes")
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        packed = packed.contiguous()
+        rc = L.srx_merge_topk_packed(dev.index or 0, _ptr(packed), nq, n_lists, k, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                     _ptr(ws), ws.numel(), _stream_ptr(torch, dev))
+        _capi.check(rc, "srx_merge_topk_packed")
+    return out

@@ -21,6 +21,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _pack(doc, score, count):
+    nq, k = doc.shape
+    out = torch.empty((nq, 2 * k + 1), dtype=torch.int32)
+    out[:, :k] = doc
+    out[:, k:2 * k] = score.view(torch.int32)
+    out[:, 2 * k] = count
+    return out
+
+
+def _merge_packed(packed, k):
+    g_doc = packed[:, :, :k]
+    g_score = packed[:, :, k:2 * k].contiguous().view(torch.float32)
+    g_count = packed[:, :, 2 * k]
+    return _merge_numpy(g_doc, g_score, g_count, k)
+
+
 def _merge_numpy(g_doc, g_score, g_count, k):
     """Reference merge: union of the per-shard lists, ranked (score desc, doc asc), top k, padded."""
     W, nq, _ = g_doc.shape
@@ -68,7 +84,7 @@ def _worker(rank, world, port, ret):
         d = np.where(d >= 0, d + a, -1).astype(np.int32)  # doc_base
         return torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(n)
 
-    searcher = sparse_rx.ShardedSearcher(local_search, _merge_numpy)
+    searcher = sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed)
     d, s, n = searcher.search(*(torch.from_numpy(x) for x in q), k)
     ed, es, en = oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf_ref, q[0], q[1], q[2], k, 1.2, 0.75, avgdl_ref)
     ok = (np.array_equal(n.numpy(), en) and np.array_equal(d.numpy(), ed)

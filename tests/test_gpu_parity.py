@@ -259,6 +259,12 @@ def test_merge_topk_matches_single_shard(rx):
                                        torch.stack([p[2] for p in parts]), k, gathered=True)
         torch.cuda.synchronize()
         _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"gathered shards={shards}")
+        # the packed single-buffer exchange format [shards, nq, 2k+1]
+        from sparse_rx.index import merge_topk_packed_device, pack_results
+        packed = torch.stack([pack_results(*p) for p in parts])
+        d, s, n = merge_topk_packed_device(packed, k)
+        torch.cuda.synchronize()
+        _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"packed shards={shards}")
 
 
 def test_impacts_bit_exact(rx):
