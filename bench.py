@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
+    ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL all-gather + packed merge) with world size 1")
     args = ap.parse_args()
@@ -137,7 +138,7 @@ def main():
     nnz_local = int(cols.numel())
 
     host_csr = None
-    want_cpu = (not args.no_cpu_baseline) and world == 1
+    want_cpu = (not args.no_cpu_baseline) and world == 1  # also in --force-dist rehearsals: verifies the exchange path
     if want_cpu:
         indptr = torch.zeros(shard_docs + 1, dtype=torch.int64, device=dev)
         indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=shard_docs), 0)
@@ -164,13 +165,15 @@ def main():
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))
-    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + ONE RCCL all-gather of the packed per-shard top-k + merge
-    searcher.force_exchange = args.force_dist
     ix_search = ix.search_device
-    ix.search_device = lambda a, b, c, kk: ix_search(a, b, c, kk, out=out)  # reuse the output tensors every step
+    if dist is None:
+        ix.search_device = lambda a, b, c, kk: ix_search(a, b, c, kk, out=out)  # reuse the output tensors every step
+
+    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of the packed per-shard top-k + merge
+    searcher.force_exchange = args.force_dist
 
     def step():
-        return searcher.search(qp, qt, qw, k)
+        return searcher.search(qp, qt, qw, k, chunks=args.chunks, q_ptr_host=q_ptr)
 
     def barrier():
         if dist is not None:

@@ -78,19 +78,62 @@ class ShardedSearcher:
         from .index import merge_topk_packed_device, pack_results
         return cls(index.search_device, pack_results, merge_topk_packed_device, group)
 
-    def search(self, q_ptr, q_term, q_weight, k: int):
+    def search(self, q_ptr, q_term, q_weight, k: int, chunks: int = 0, q_ptr_host=None):
+        """One batch.  Optionally (chunks > 1) the batch is cut into sub-batches: the all-gather + merge of
+        sub-batch i runs on a second HIP stream while sub-batch i+1 is scored (default off: one exchange per batch).  q_ptr_host: the
+        same q_ptr on the host (NumPy / CPU tensor), to cut sub-batches without a device-to-host sync."""
         import torch
         import torch.distributed as dist
-        doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1) and not getattr(self, "force_exchange", False):
-            return doc, score, count
+        exchange = (dist.is_initialized() and dist.get_world_size(self.group) > 1) or getattr(self, "force_exchange", False)
+        if not exchange:
+            return self.local_search(q_ptr, q_term, q_weight, k)
         world = dist.get_world_size(self.group)
+        nq = q_ptr.shape[0] - 1
+        on_gpu = q_ptr.is_cuda
+        if chunks <= 0:
+            chunks = 1  # measured on one GPU: cutting the batch costs more (under-filled launches) than it can hide
+        if chunks == 1 or not on_gpu:
+            doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
+            return self._exchange(doc, score, count, k, world, slot=0)
+        # sub-batch boundaries (queries are rows of a CSR: slice q_ptr, rebase, slice terms/weights)
+        dev = q_ptr.device
+        bounds = [(nq * i) // chunks for i in range(chunks + 1)]
+        qp_host = q_ptr_host if q_ptr_host is not None else q_ptr.cpu()  # the term offsets of the cut points
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        side.wait_stream(main)
+        outs = []
+        for i in range(chunks):
+            a, b = bounds[i], bounds[i + 1]
+            ta, tb = int(qp_host[a]), int(qp_host[b])
+            sub_ptr = (q_ptr[a: b + 1] - ta).contiguous()
+            part = self.local_search(sub_ptr, q_term[ta:tb], q_weight[ta:tb], k)  # on the main stream, fresh output tensors
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                outs.append(self._exchange(*part, k, world, slot=i))
+                for t in part:
+                    t.record_stream(side)
+        main.wait_stream(side)
+        for o in outs:
+            for t in o:
+                t.record_stream(main)
+        return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
+
+    def _exchange(self, doc, score, count, k: int, world: int, slot: int):
+        import torch
+        import torch.distributed as dist
         nq = count.shape[0]
         mine = self.pack(doc, score, count)  # [nq, 2k+1] i32: nq*(8k+4) bytes per rank
-        key = (world, nq, k, mine.device)
-        if self._buf is None or self._buf[0] != key:
-            self._buf = (key, torch.empty((world, nq, 2 * k + 1), dtype=torch.int32, device=mine.device))
-        g = self._buf[1]
+        key = (world, nq, k, mine.device, slot)
+        if self._buf is None:
+            self._buf = {}
+        g = self._buf.get(key)
+        if g is None:
+            g = self._buf[key] = torch.empty((world, nq, 2 * k + 1), dtype=torch.int32, device=mine.device)
         # RCCL over xGMI on the GPU build; output = concatenation along dim 0 (the form every backend accepts)
         dist.all_gather_into_tensor(g.view(world * nq, 2 * k + 1), mine, group=self.group)
         return self.merge(g, k)
