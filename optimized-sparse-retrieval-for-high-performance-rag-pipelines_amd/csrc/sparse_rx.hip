@@ -517,33 +517,65 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
         for (int i = tid; i < G / 4; i += THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    for (int i = 0; i < nt; ++i) {
+    // Batches of 2048 postings (two dwordx4 stripes = 8 per thread) are enumerated term-major; the loads of batch n+1
+    // are issued before batch n is accumulated, across term boundaries too, so 2 x 16 KB per workgroup stay in flight
+    // and a term's load latency hides behind the previous term's work.  A barrier separates consecutive batches of
+    // different terms (the next term may touch the same doc).
+    constexpr int NB = 8;                 // postings per thread per batch
+    constexpr int BATCH = THREADS * NB;   // 2048
+    auto next_term = [&](int i) {  // first term index >= i with postings in this tile (uniform), nt if none
+        while (i < nt && S.m_len[i] == 0) ++i;
+        return i;
+    };
+    auto load_batch = [&](int i, int o, int (&d)[NB], float (&v)[NB]) {
         const int len = S.m_len[i];
-        if (len == 0) continue;  // uniform
         const int64_t start = S.m_start[i];
-        const float idf = S.m_idf[i], qw = S.m_qw[i];
-        for (int p0 = 0; p0 < len; p0 += THREADS * 4) {
-            int d[4];
-            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = p0 + r * THREADS + tid;
-                d[r] = -1;
-                v[r] = 0.f;
-                if (p < len) {
-                    d[r] = post_doc[start + p];
-                    v[r] = load_val(post_val, start + p);
-                }
-            }
+        for (int h = 0; h < NB / 4; ++h) {
+            const int p = o + h * (THREADS * 4) + tid * 4;  // my 4 consecutive postings of this stripe
+            const int64_t g = (p < len) ? start + p : start;  // idle threads re-read the run's head (always valid)
+            load4(post_doc + g, 0, d[4 * h], d[4 * h + 1], d[4 * h + 2], d[4 * h + 3]);
+            load4(post_val + g, 0, v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (d[r] >= 0) {
-                    const int o = d[r] - tile_base;
-                    acc[o] = acc[o] + (v[r] * idf) * qw;  // docs unique within a term: no conflict
-                }
+            for (int c = 0; c < 4; ++c)
+                if (p + c >= len) d[4 * h + c] = -1;
         }
-        __syncthreads();  // next term may touch the same doc
+    };
+    auto add_batch = [&](int i, const int (&d)[NB], const float (&v)[NB]) {
+        const float idf = S.m_idf[i], qw = S.m_qw[i];
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+            if (d[r] >= 0) {
+                const int o = d[r] - tile_base;
+                acc[o] = acc[o] + (v[r] * idf) * qw;  // docs unique within a term: no conflict
+            }
+    };
+    int ci = next_term(0), co = 0;
+    if (ci >= nt) return;
+    int dA[NB], dB[NB];
+    float vA[NB], vB[NB];
+    load_batch(ci, co, dA, vA);
+    for (;;) {
+        // successor batch
+        int ni = ci, no = co + BATCH;
+        if (no >= S.m_len[ci]) {
+            ni = next_term(ci + 1);
+            no = 0;
+        }
+        const bool more = ni < nt;
+        if (more) load_batch(ni, no, dB, vB);
+        add_batch(ci, dA, vA);
+        if (!more) break;
+        if (ni != ci) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            dA[r] = dB[r];
+            vA[r] = vB[r];
+        }
+        ci = ni;
+        co = no;
     }
+    __syncthreads();
 }
 
 __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k) {
