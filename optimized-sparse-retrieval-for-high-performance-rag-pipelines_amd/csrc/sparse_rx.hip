@@ -6,19 +6,24 @@
 //   fast_topk_selection  rag_system/core/retrieval.py:79-92      (+ score>0 filter :292-296)
 //
 // Design: the index is term-major (CSC) with a tile skip table.  A query's doc range is cut
-// into *units* (supertiles of 2^s docs).  Two tiers score them, a merge kernel ranks:
-//   tier 1  srx_wave_kernel   ONE WAVEFRONT per (query, split): streams each term's run of the unit from HBM
-//           (coalesced, terms ascending, 64 postings per step), resolves doc -> slot in a wave-private LDS hash
-//           table with ds_cmpst, then adds contributions with ds_add_f32 in step order.  LDS executes one
-//           wave's instructions in order, so per-doc sums are accumulated in ascending term id without any
-//           barrier -- bit-identical to the reference's CSR row order.  A lazy top-k list lives in LDS; an
-//           exact wave-level radix select shrinks it when it fills.  Units with too many postings (hot
-//           terms), queries with > 64 terms and k > 128 are flagged for tier 2.
-//   tier 2  srx_score_kernel  one 256-thread workgroup per (query, split): block-level hash units of up to 4096
-//           postings, a greedy tile packer, and dense fp32 accumulators acc[G] in LDS for tiles whose postings
-//           exceed that (barrier between terms keeps the summation order).  Handles everything.
-//   merge   srx_merge_kernel  exact top-k over the per-split lists + bitonic rank by (score desc, doc asc).
-// No MFMA (sparse gather/reduce, HBM-bound), no global float atomics (order must be deterministic).
+// into *units* of a few tiles.  Two tiers score them, a merge kernel ranks:
+//   tier 1  srx_wave_kernel   ONE WAVEFRONT per (query, split), no barriers.  Each query term owns a group of lanes;
+//           a lane streams 4 consecutive postings per dwordx4 load, the next unit's loads are in flight while this
+//           unit is scored from registers.  A wave-private LDS bitmap (1 bit per doc of the unit, ds_or_rtn) tells
+//           which docs are matched by more than one term; every other posting is a single-term doc whose score is
+//           its own contribution.  Postings of multi-term docs are parked in LDS and summed in ascending term id
+//           (one wave's DS instructions execute in order), bit-identical to the reference's CSR row order.  A lazy
+//           top-k list lives in LDS; an exact wave-level radix select shrinks it when it fills; the initial
+//           threshold comes from per-term score bounds stored in the index.  Units that do not fit (long runs,
+//           many duplicates), queries with > 64 terms and k > 128 are flagged for tier 2.
+//   tier 2  srx_score_kernel  a persistent grid of 256-thread workgroups drains the worklist of flagged (query,
+//           split) blocks: block-level LDS hash units of up to 4096 postings, a greedy tile packer, and dense fp32
+//           accumulators acc[G] in LDS for tiles whose postings exceed that (barrier between terms keeps the
+//           summation order).  Handles everything.
+//   merge   srx_merge_kernel  exact top-k over the per-split / per-tier / per-shard lists + bitonic rank by
+//           (score desc, doc asc).  Queries that tier 1 finished on its own are ranked there and skipped here.
+// No MFMA (sparse gather/reduce, HBM-bound), no float atomics (LDS ds_add_f32 serialises at ~192 cycles per
+// wave-instruction on gfx950, and sums must be deterministic).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no fused multiply-add: the reference's
 // arithmetic is separate fp32 multiply / add / IEEE divide).
@@ -1071,7 +1076,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int row = ix.n_tiles + 1;
 
     const int bm_words = max(256, ((tpu << ix.tile_log2) + 31) >> 5);  // the launch's dynamic LDS holds bm_words + 64 words
-    if (lane < 4) S.cnt[lane] = 0;
+    if (lane < 4) S.cnt[lane] = (lane == 2) ? 0xFFFFFFFFu : 0u;
     for (int i = lane; i < (bm_words + 64) / 4; i += 64) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
     wsync();
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
             const int dummy = (bm_words + lane) << 5;
             if (mcnt > (unsigned)(W_MCAP - 2 * W_DUPCAP)) {  // uniform: room for this unit's multi-term postings
-                tk = wave_resolve_multi(S, mcnt, k, tk);
+                tk = wave_resolve_multi(S, uniu(S.cnt[1]), k, tk);
                 tk.count = uniu(tk.count);
                 tk.tau = uniu(tk.tau);
                 mcnt = 0;
@@ -1174,24 +1179,28 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 old[r] = atomicOr(&bm[(unsigned)d[r] >> 5], 1u << (d[r] & 31));
             }
             STAMP(2);  // wait for the unit's postings + pass 1
+            unsigned anyd = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if ((old[r] >> (d[r] & 31)) & 1u) {  // rare: an earlier posting of this unit has the same doc
-                    const unsigned e = atomicAdd(&S.cnt[0], 1u);
-                    if (e < (unsigned)W_DUPCAP) S.dupoff[e] = d[r];
-                    const unsigned p = atomicAdd(&S.cnt[1], 1u);
-                    if (p < (unsigned)W_MCAP) {
-                        S.ml_d[p] = d[r] + ubase;
-                        S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
-                        S.ml_t[p] = tslot;
-                    }
-                    v[r] = 0.0f;
-                }
-            }
-            wsync();
-            const unsigned nd = uniu(S.cnt[0]);
+            for (int r = 0; r < NR; ++r) anyd |= (old[r] >> (d[r] & 31)) & 1u;
             bool dense = false;
-            if (nd != 0) {  // uniform
+            if (__ballot(anyd != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms (~2 units in 3)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if ((old[r] >> (d[r] & 31)) & 1u) {  // rare lanes: an earlier posting of this unit has the same doc
+                        const unsigned e = atomicAdd(&S.cnt[0], 1u);
+                        if (e < (unsigned)W_DUPCAP) S.dupoff[e] = d[r];
+                        const unsigned p = atomicAdd(&S.cnt[1], 1u);
+                        atomicMin(&S.cnt[2], p);  // first pending-list slot this unit took (for the dense roll-back)
+                        if (p < (unsigned)W_MCAP) {
+                            S.ml_d[p] = d[r] + ubase;
+                            S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
+                            S.ml_t[p] = tslot;
+                        }
+                        v[r] = 0.0f;
+                    }
+                }
+                wsync();
+                const unsigned nd = uniu(S.cnt[0]);
                 if (nd <= (unsigned)W_DUPCAP) {
                     for (unsigned e = 0; e < nd; ++e) {  // uniform loop, about one entry per unit on sparse queries
                         const int dd = uni(S.dupoff[e]);
@@ -1206,16 +1215,19 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                             }
                         }
                     }
+                    mcnt += 2 * nd;  // upper bound of the pending postings; the exact count lives in S.cnt[1]
                 } else {
-                    dense = true;  // too many multi-term docs for this path: drop what was parked, tier 2 takes the unit
+                    // too many multi-term docs for this path: drop what this unit parked, tier 2 takes the unit
+                    dense = true;
+                    const unsigned first = uniu(S.cnt[2]);
+                    wsync();
+                    if (lane == 0) S.cnt[1] = first;
                 }
                 wsync();
                 if (lane == 0) {
                     S.cnt[0] = 0;
-                    if (dense) S.cnt[1] = mcnt;
+                    S.cnt[2] = 0xFFFFFFFFu;
                 }
-                wsync();
-                mcnt = uniu(S.cnt[1]);
             }
             STAMP(3);  // duplicate resolution
 #pragma unroll
@@ -1303,7 +1315,10 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         default: run(IntC<6>{}); break;
     }
     if ((dbg & 4) && sink == 0x7F123457) cand_count[list] = sink;  // keeps the loads of the timing experiment alive
-    if (mcnt > 0) tk = wave_resolve_multi(S, mcnt, k, tk);
+    if (mcnt > 0) {
+        wsync();
+        tk = wave_resolve_multi(S, uniu(S.cnt[1]), k, tk);
+    }
     unsigned count = tk.count;
     if (count > (unsigned)k) {
         wave_list_select(S, count, k);
