@@ -357,3 +357,30 @@ def test_registry_twin_golden(rx, golden_dir, tmp_path):
         assert np.array_equal(np.array(list(first[qid].values()), np.float32), np.array(list(exp[qid].values()), np.float32)), qid
     pr.close()
     pr2.close()
+
+
+def test_fuzz_shapes_vs_oracle(rx):
+    """Randomised shapes: query length 1..64 (all lane-group sizes), correlated terms (many multi-term docs, the
+    parking / resolve / dense roll-back paths), units of 1..8 tiles, k from 1 to 128 (tier 1) and above (tier 2)."""
+    from sparse_rx import synth
+    rng = np.random.default_rng(2025)
+    for trial in range(40):
+        n_docs = int(rng.integers(3_000, 60_000))
+        vocab = int(rng.integers(50, 4_000))
+        draws = int(rng.integers(5, 60))
+        s = float(rng.choice([0.0, 0.6, 1.0, 1.3]))
+        c = synth.zipf_corpus_np(n_docs, vocab, draws, seed=1000 + trial, s=s) if s > 0 else \
+            synth.uniform_corpus_np(n_docs, vocab, min(draws, vocab), seed=1000 + trial)
+        _, idf, avgdl = synth.corpus_stats(c)
+        nq = 40
+        terms = int(rng.integers(1, 65))
+        q = synth.queries_np(nq, vocab, min(terms, vocab), seed=2000 + trial, dist="zipf" if s > 0 else "uniform", s=max(s, 0.5))
+        tile_log2 = int(rng.integers(6, 13))
+        ix = _dev_index(rx, c, idf, avgdl, tile_log2=tile_log2)
+        for _ in range(3):
+            ut = int(rng.integers(1, 9))
+            k = int(rng.choice([1, 5, 100, 128, 129, 300]))
+            ix.set_opts(unit_tiles=ut, target_blocks=int(rng.choice([0, 1, 10_000])))
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k),
+                          f"fuzz trial={trial} docs={n_docs} V={vocab} draws={draws} s={s} terms={terms} tile={tile_log2} ut={ut} k={k}")
+        ix.close()
