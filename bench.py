@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
+    ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="N > 1: how per-shard top-k lists meet")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL all-gather + packed merge) with world size 1")
@@ -171,6 +172,7 @@ def main():
 
     searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of the packed per-shard top-k + merge
     searcher.force_exchange = args.force_dist
+    searcher.mode = args.exchange
 
     def step():
         return searcher.search(qp, qt, qw, k, chunks=args.chunks, q_ptr_host=q_ptr)
@@ -239,7 +241,7 @@ def main():
         "config": {"workload": f"{wl_name}: {n_docs} docs x {V} vocab, {w['nnz_per_doc']} nnz/doc, "
                                f"{nq}-query batch x {w['terms']} terms, k={k}",
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_local * world if world > 1 else nnz_local, "n_queries": nq, "k": k,
-                   "sharding": f"doc-range x{world}" + (" + one RCCL all-gather of packed per-shard top-k" if (world > 1 or args.force_dist) else ""),
+                   "sharding": f"doc-range x{world}" + ((" + RCCL all-to-all of packed per-shard top-k, merge of the own query block, all-gather of merged rows" if args.exchange == "a2a" else " + one RCCL all-gather of packed per-shard top-k") if (world > 1 or args.force_dist) else ""),
                    "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>" if kind != "splade" else "srx_score_kernel<__half> (tier 2: k > 128)",

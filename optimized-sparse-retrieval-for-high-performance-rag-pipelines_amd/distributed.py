@@ -124,16 +124,40 @@ class ShardedSearcher:
         return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
 
     def _exchange(self, doc, score, count, k: int, world: int, slot: int):
+        """Per-shard top-k -> global top-k.
+
+        mode "a2a" (default): the queries are cut into `world` contiguous blocks; ONE all-to-all sends every rank the
+        per-shard lists of ITS block ([world, nq/world, 2k+1] per rank: 1/world of the all-gather traffic and of the
+        merge work), it merges them, and ONE all-gather of the merged rows ([nq/world, 2k+1] per rank) replicates the
+        final result.  mode "allgather": one all-gather of everything, every rank merges every query."""
         import torch
         import torch.distributed as dist
         nq = count.shape[0]
+        row = 2 * k + 1
         mine = self.pack(doc, score, count)  # [nq, 2k+1] i32: nq*(8k+4) bytes per rank
-        key = (world, nq, k, mine.device, slot)
         if self._buf is None:
             self._buf = {}
-        g = self._buf.get(key)
-        if g is None:
-            g = self._buf[key] = torch.empty((world, nq, 2 * k + 1), dtype=torch.int32, device=mine.device)
-        # RCCL over xGMI on the GPU build; output = concatenation along dim 0 (the form every backend accepts)
-        dist.all_gather_into_tensor(g.view(world * nq, 2 * k + 1), mine, group=self.group)
-        return self.merge(g, k)
+        mode = getattr(self, "mode", "a2a")
+        if mode == "allgather":
+            key = ("ag", world, nq, k, mine.device, slot)
+            g = self._buf.get(key)
+            if g is None:
+                g = self._buf[key] = torch.empty((world, nq, row), dtype=torch.int32, device=mine.device)
+            # RCCL over xGMI on the GPU build; output = concatenation along dim 0 (the form every backend accepts)
+            dist.all_gather_into_tensor(g.view(world * nq, row), mine, group=self.group)
+            return self.merge(g, k)
+        # ---- all-to-all: rank j merges query block j ----
+        blk = (nq + world - 1) // world
+        key = ("a2a", world, nq, k, mine.device, slot)
+        bufs = self._buf.get(key)
+        if bufs is None:
+            bufs = self._buf[key] = (torch.zeros((world * blk, row), dtype=torch.int32, device=mine.device),   # send (padded)
+                                     torch.empty((world, blk, row), dtype=torch.int32, device=mine.device),    # lists of my block
+                                     torch.empty((world * blk, row), dtype=torch.int32, device=mine.device))   # merged rows, all blocks
+        send, recv, allrows = bufs
+        send[:nq] = mine  # rows nq .. world*blk-1 stay zero = empty lists (count 0)
+        dist.all_to_all_single(recv.view(world * blk, row), send, group=self.group)
+        mdoc, mscore, mcount = self.merge(recv, k)  # my block: [blk, k]
+        dist.all_gather_into_tensor(allrows, self.pack(mdoc, mscore, mcount), group=self.group)
+        out = allrows[:nq]
+        return (out[:, :k].contiguous(), out[:, k:2 * k].contiguous().view(torch.float32), out[:, 2 * k].contiguous())

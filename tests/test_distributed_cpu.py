@@ -58,7 +58,7 @@ def _merge_numpy(g_doc, g_score, g_count, k):
     return out_d, out_s, out_c
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, mode, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,6 +85,7 @@ def _worker(rank, world, port, ret):
         return torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(n)
 
     searcher = sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed)
+    searcher.mode = mode
     d, s, n = searcher.search(*(torch.from_numpy(x) for x in q), k)
     ed, es, en = oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf_ref, q[0], q[1], q[2], k, 1.2, 0.75, avgdl_ref)
     ok = (np.array_equal(n.numpy(), en) and np.array_equal(d.numpy(), ed)
@@ -93,13 +94,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_search_matches_single_shard(world):
+@pytest.mark.parametrize("world,mode", [(2, "a2a"), (3, "a2a"), (2, "allgather"), (3, "allgather")])
+def test_sharded_search_matches_single_shard(world, mode):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
         ret = m.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, mode, ret)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
