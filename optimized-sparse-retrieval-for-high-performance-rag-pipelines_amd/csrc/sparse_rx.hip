@@ -82,10 +82,8 @@ constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bi
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 constexpr int W_R = 12;                     // postings per lane per unit held in registers (steps)
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
-constexpr int W_MSLOTS = 256;               // hash table for docs matched by several query terms
-constexpr int W_MCAP = 128;                 // pending postings of multi-term docs (resolved when the list fills)
-constexpr int W_DUPCAP = 24;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
-constexpr int W_LCAP = 256;                 // lazy top-k list capacity (>= W_KMAX + 64)
+constexpr int W_DUPCAP = 48;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
+constexpr int W_LCAP = 384;                 // lazy top-k list capacity (entries; a multiple of 64)
 constexpr int W_KMAX = 128;                 // largest k served by tier 1
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
 
@@ -822,15 +820,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct WaveShared {
-    int mkeys[W_MSLOTS];           // small hash table for docs matched by more than one query term
-    float mvals[W_MSLOTS];
     unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
     int ldoc[W_LCAP];
-    int ml_d[W_MCAP];              // pending postings of multi-term docs (doc, contribution, term slot)
-    float ml_c[W_MCAP];
-    int ml_t[W_MCAP];
-    int dupoff[W_DUPCAP];          // the current unit's duplicate postings (doc offset in the unit), broadcast to all lanes
-    unsigned cnt[4];               // [0] dup postings of the current unit, [1] pending multi-term postings
 };
 
 // Exact k-th largest of the wave's keys (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix, 256-bin LDS
@@ -982,63 +973,6 @@ __device__ __forceinline__ void wave_append(WaveShared &S, WaveTopk &tk, int k, 
     }
 }
 
-// Resolve the pending postings of multi-term docs (S.ml_*, mcnt <= W_MCAP = 128 entries, two per lane): per-doc
-// sums in a small hash table, in rounds of ascending term slot (docs are unique inside a term, so a round has no
-// intra-instruction conflicts; one wave's DS instructions execute in order across rounds).  The finished sums
-// (> 0, >= tau) enter the top-k list.  Rare (once per ~30 units), hence out of line.
-__device__ __noinline__ WaveTopk wave_resolve_multi(WaveShared &S, unsigned mcnt, int k, WaveTopk tk) {
-    const int lane = threadIdx.x;
-    wsync();
-    int md[2], mt[2];
-    float mc[2];
-    unsigned h[2];
-    bool pending[2], claimed[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const unsigned i = lane + 64 * e;
-        pending[e] = i < mcnt;
-        claimed[e] = false;
-        md[e] = pending[e] ? S.ml_d[i] : 0;
-        mc[e] = pending[e] ? S.ml_c[i] : 0.f;
-        mt[e] = pending[e] ? S.ml_t[i] : 0x7FFFFFFF;
-        h[e] = ((unsigned)md[e] * 0x9E3779B1u) >> (32 - 8);
-    }
-    while (__ballot(pending[0] || pending[1]) != 0ull) {  // one round per distinct term, ascending
-        const unsigned mine = min(pending[0] ? (unsigned)mt[0] : 0x7FFFFFFFu, pending[1] ? (unsigned)mt[1] : 0x7FFFFFFFu);
-        const int tcur = uni((int)wave_min(mine));
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (pending[e] && mt[e] == tcur) {
-                for (;;) {
-                    const int o = atomicCAS(&S.mkeys[h[e]], EMPTY_KEY, md[e]);
-                    if (o == EMPTY_KEY) {
-                        S.mvals[h[e]] = mc[e];  // first term of this doc (0 + c == c, c is never -0)
-                        claimed[e] = true;
-                        break;
-                    }
-                    if (o == md[e]) {
-                        S.mvals[h[e]] = S.mvals[h[e]] + mc[e];  // a later term: in-order read-add-store
-                        break;
-                    }
-                    h[e] = (h[e] + 1) & (W_MSLOTS - 1);
-                }
-                pending[e] = false;
-            }
-            wsync();
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float sc = claimed[e] ? S.mvals[h[e]] : 0.f;
-        const unsigned b = __float_as_uint(sc);
-        wave_append(S, tk, k, claimed[e] && sc > 0.0f && b >= tk.tau, b, md[e]);
-    }
-    wsync();
-    reinterpret_cast<int4 *>(S.mkeys)[lane] = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
-    wsync();
-    return tk;
-}
-
 template <int L>
 struct IntC {
     static constexpr int value = L;
@@ -1076,12 +1010,9 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
     const int row = ix.n_tiles + 1;
 
     const int bm_words = max(256, ((tpu << ix.tile_log2) + 31) >> 5);  // the launch's dynamic LDS holds bm_words + 64 words
-    if (lane < 4) S.cnt[lane] = (lane == 2) ? 0xFFFFFFFFu : 0u;
     for (int i = lane; i < (bm_words + 64) / 4; i += 64) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = lane; i < W_MSLOTS; i += 64) S.mkeys[i] = EMPTY_KEY;
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
-    unsigned mcnt = 0;       // wave-uniform: pending multi-term postings in S.ml_*
     int sink = 0;            // debug only
 #ifdef SRX_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
@@ -1163,12 +1094,9 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             const int ubase = (su * tpu) << ix.tile_log2;
             const int rem = len - 4 * jl;  // register r holds posting pos(r) = (r / 4) * 4 LPT + r % 4 of my lane's stripe
             const int dummy = (bm_words + lane) << 5;
-            if (mcnt > (unsigned)(W_MCAP - 2 * W_DUPCAP)) {  // uniform: room for this unit's multi-term postings
-                tk = wave_resolve_multi(S, uniu(S.cnt[1]), k, tk);
-                tk.count = uniu(tk.count);
-                tk.tau = uniu(tk.tau);
-                mcnt = 0;
-                if (lane == 0) S.cnt[1] = 0;
+            if (tk.count > (unsigned)(W_LCAP - 64 - W_DUPCAP)) {  // uniform, rare: room for this unit's multi-term docs
+                tk.tau = uniu(wave_list_select(S, tk.count, k));
+                tk.count = (unsigned)k;
             }
             unsigned old[NR];
 #pragma unroll
@@ -1179,54 +1107,53 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 old[r] = atomicOr(&bm[(unsigned)d[r] >> 5], 1u << (d[r] & 31));
             }
             STAMP(2);  // wait for the unit's postings + pass 1
-            unsigned anyd = 0;
+            unsigned dm = 0;  // bit r: posting r found its doc's bit already set (an earlier posting matched the same doc)
 #pragma unroll
-            for (int r = 0; r < NR; ++r) anyd |= (old[r] >> (d[r] & 31)) & 1u;
+            for (int r = 0; r < NR; ++r) dm |= ((old[r] >> (d[r] & 31)) & 1u) << r;
             bool dense = false;
-            if (__ballot(anyd != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms (~2 units in 3)
+            if (__ballot(dm != 0) != 0ull) {  // uniform: some doc of this unit is matched by several terms (~2 units in 3)
+                unsigned ndup = 0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    if ((old[r] >> (d[r] & 31)) & 1u) {  // rare lanes: an earlier posting of this unit has the same doc
-                        const unsigned e = atomicAdd(&S.cnt[0], 1u);
-                        if (e < (unsigned)W_DUPCAP) S.dupoff[e] = d[r];
-                        const unsigned p = atomicAdd(&S.cnt[1], 1u);
-                        atomicMin(&S.cnt[2], p);  // first pending-list slot this unit took (for the dense roll-back)
-                        if (p < (unsigned)W_MCAP) {
-                            S.ml_d[p] = d[r] + ubase;
-                            S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
-                            S.ml_t[p] = tslot;
-                        }
-                        v[r] = 0.0f;
-                    }
-                }
-                wsync();
-                const unsigned nd = uniu(S.cnt[0]);
-                if (nd <= (unsigned)W_DUPCAP) {
-                    for (unsigned e = 0; e < nd; ++e) {  // uniform loop, about one entry per unit on sparse queries
-                        const int dd = uni(S.dupoff[e]);
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            if (d[r] == dd && v[r] != 0.0f) {  // rare: the first posting of a multi-term doc
-                                const unsigned p = atomicAdd(&S.cnt[1], 1u);
-                                S.ml_d[p] = d[r] + ubase;  // p < W_MCAP: room for 2 * W_DUPCAP was made above
-                                S.ml_c[p] = 0.0f + (v[r] * my_idf) * my_qw;
-                                S.ml_t[p] = tslot;
-                                v[r] = 0.0f;
-                            }
-                        }
-                    }
-                    mcnt += 2 * nd;  // upper bound of the pending postings; the exact count lives in S.cnt[1]
+                for (int r = 0; r < NR; ++r) ndup += (unsigned)__popcll(__ballot(((dm >> r) & 1u) != 0u));
+                if (ndup > (unsigned)W_DUPCAP) {
+                    dense = true;  // too many multi-term docs for this path: tier 2 takes the unit (nothing was emitted)
                 } else {
-                    // too many multi-term docs for this path: drop what this unit parked, tier 2 takes the unit
-                    dense = true;
-                    const unsigned first = uniu(S.cnt[2]);
-                    wsync();
-                    if (lane == 0) S.cnt[1] = first;
-                }
-                wsync();
-                if (lane == 0) {
-                    S.cnt[0] = 0;
-                    S.cnt[2] = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        // postings that found their doc's bit set, still unresolved (v != 0)
+                        unsigned long long m = __ballot(((dm >> r) & 1u) != 0u && v[r] != 0.0f);
+                        while (m != 0ull) {  // uniform loop, about one doc per unit on sparse queries
+                            const int src = __ffsll((long long)m) - 1;
+                            const int dd = __builtin_amdgcn_readlane(d[r], src);  // the doc (offset in the unit), wave-uniform
+                            // A doc occurs at most once per term, hence at most once per lane: pick up my posting of it
+                            // (if any) and blank it, so that the single-term screening below never sees it.
+                            float myv = 0.0f;
+#pragma unroll
+                            for (int r2 = 0; r2 < NR; ++r2) {
+                                const bool hit = d[r2] == dd;
+                                myv = hit ? v[r2] : myv;
+                                v[r2] = hit ? 0.0f : v[r2];
+                            }
+                            const float myc = 0.0f + (myv * my_idf) * my_qw;
+                            // exact score: contributions in ascending term id = ascending lane (term slots own lane groups)
+                            unsigned long long mm = __ballot(myv != 0.0f);
+                            float sum = 0.0f;
+                            while (mm != 0ull) {
+                                const int l2 = __ffsll((long long)mm) - 1;
+                                sum = sum + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(myc), l2));
+                                mm &= mm - 1ull;
+                            }
+                            const unsigned b = __float_as_uint(sum);
+                            if (sum > 0.0f && b >= tk.tau) {  // uniform; room for W_DUPCAP entries was made above
+                                if (lane == 0) {
+                                    S.lbits[tk.count] = b;
+                                    S.ldoc[tk.count] = dd + ubase;
+                                }
+                                ++tk.count;
+                            }
+                            m = __ballot(((dm >> r) & 1u) != 0u && v[r] != 0.0f);
+                        }
+                    }
                 }
             }
             STAMP(3);  // duplicate resolution
@@ -1247,13 +1174,20 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                     vthr = (my_idf > 0.0f && my_qw > 0.0f) ? fmaxf(((tau_f / my_qw) / my_idf) * 0.99999f, __uint_as_float(1u))
                                                          : __builtin_inff();
                 }
+                // one test per unit in the steady state: the lane's largest value (v_max3 tree) against its threshold
+                float vmax = v[0];
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const bool pass = v[r] >= vthr;
-                    if (__ballot(pass) != 0ull) {  // uniform, rare after warm-up
-                        const float c = 0.0f + (v[r] * my_idf) * my_qw;
-                        const unsigned b = __float_as_uint(c);
-                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r] + ubase);
+                for (int r = 1; r + 1 < NR; r += 2) vmax = fmaxf(fmaxf(vmax, v[r]), v[r + 1]);
+                if constexpr (NR % 2 == 0) vmax = fmaxf(vmax, v[NR - 1]);
+                if (__ballot(vmax >= vthr) != 0ull) {  // uniform, rare after warm-up
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const bool pass = v[r] >= vthr;
+                        if (__ballot(pass) != 0ull) {
+                            const float c = 0.0f + (v[r] * my_idf) * my_qw;
+                            const unsigned b = __float_as_uint(c);
+                            wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r] + ubase);
+                        }
                     }
                 }
             }
@@ -1315,10 +1249,6 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
         default: run(IntC<6>{}); break;
     }
     if ((dbg & 4) && sink == 0x7F123457) cand_count[list] = sink;  // keeps the loads of the timing experiment alive
-    if (mcnt > 0) {
-        wsync();
-        tk = wave_resolve_multi(S, uniu(S.cnt[1]), k, tk);
-    }
     unsigned count = tk.count;
     if (count > (unsigned)k) {
         wave_list_select(S, count, k);
