@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="N > 1: how per-shard top-k lists meet")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL all-gather + packed merge) with world size 1")
@@ -173,6 +174,7 @@ def main():
     searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of the packed per-shard top-k + merge
     searcher.force_exchange = args.force_dist
     searcher.mode = args.exchange
+    searcher.overlap = not args.no_overlap
 
     def step():
         return searcher.search(qp, qt, qw, k, chunks=args.chunks, q_ptr_host=q_ptr)
@@ -190,9 +192,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    t_submit = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"[bench] host submit time {1e3 * t_submit / args.steps:.3f} ms/step of {1e3 * elapsed / args.steps:.3f} ms/step")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

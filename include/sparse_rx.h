@@ -148,6 +148,15 @@ int srx_merge_topk_packed(int32_t device, const int32_t *packed, int32_t nq, int
                           int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
                           int64_t workspace_bytes, void *stream);
 
+/* The same rows as outputs, so that no packing / unpacking kernels are needed around the exchange:
+ * srx_search_packed writes each query's result as one row [k doc ids][k score bits][count] of out_packed[nq][2k+1]
+ * (same results as srx_search: retrieval.py:256-284), and srx_merge_topk_packed_out merges gathered packed rows
+ * [n_lists][nq][2k+1] into packed rows [nq][2k+1]. */
+int srx_search_packed(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                      int32_t k, int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream);
+int srx_merge_topk_packed_out(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
+                              int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- device-side index construction helpers ------------------------------------------------------ */
 
 /* impact[p] = (tf[p]*(k1+1)) / (tf[p] + k1*(1-b + b*doc_len[post_doc[p]]/avgdl)), fp32, the reference's

@@ -988,7 +988,8 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                                                       float *__restrict__ cand_score,
                                                       int32_t *__restrict__ cand_count, int64_t doc_base,
                                                       int32_t *__restrict__ out_doc, float *__restrict__ out_score,
-                                                      int32_t *__restrict__ out_count) {
+                                                      int32_t *__restrict__ out_count, int64_t out_row_stride,
+                                                      int64_t out_cnt_stride) {
     __shared__ WaveShared S;
     extern __shared__ __attribute__((aligned(16))) unsigned bm[];  // doc bitmap of the current unit: bm_words words (>= 256)
     const int lane = threadIdx.x;
@@ -1285,7 +1286,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 wsync();
             }
         }
-        const int64_t oo = (int64_t)q * k;
+        const int64_t oo = (int64_t)q * out_row_stride;
         for (unsigned i = lane; i < (unsigned)k; i += 64) {
             if (i < count) {
                 const unsigned long long x = K[i];
@@ -1297,7 +1298,7 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
             }
         }
         if (lane == 0) {
-            out_count[q] = (int)count;
+            out_count[(int64_t)q * out_cnt_stride] = (int)count;
             cand_count[list] = -1;  // tells the merge kernel this query is final
         }
         return;
@@ -1332,7 +1333,8 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
                                                             int gathered, int64_t row_stride, int64_t cnt_stride,
                                                             int64_t doc_base, int32_t *__restrict__ out_doc,
                                                             float *__restrict__ out_score,
-                                                            int32_t *__restrict__ out_count) {
+                                                            int32_t *__restrict__ out_count, int64_t out_row_stride,
+                                                            int64_t out_cnt_stride) {
     __shared__ MergeShared M;
     const int tid = threadIdx.x;
     const int q = blockIdx.x / n_groups;
@@ -1401,7 +1403,7 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
             __syncthreads();
         }
     }
-    const int64_t o = (int64_t)q * k;
+    const int64_t o = (int64_t)q * out_row_stride;  // final rows may live in a strided (packed) buffer
     for (unsigned i = tid; i < (unsigned)k; i += THREADS) {
         if (i < cnt) {
             const unsigned long long x = M.sortkey[i];
@@ -1412,7 +1414,7 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
             out_score[o + i] = 0.0f;
         }
     }
-    if (tid == 0) out_count[q] = (int)cnt;
+    if (tid == 0) out_count[(int64_t)q * out_cnt_stride] = (int)cnt;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1584,9 +1586,10 @@ SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int3
     return lists * k * 8 + lists * 4 + (int64_t)nq * p.ovf_words * 4 + 4 * (1 + (int64_t)nq * p.n_splits) + 256;
 }
 
-SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
-                       int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
-                       int64_t workspace_bytes, void *stream_v) {
+namespace {
+int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, int64_t ors, int64_t ocs,
+                void *workspace, int64_t workspace_bytes, void *stream_v) {
     if (!ix) return fail(SRX_ERR_INVALID, "srx_search: null index%s");
     if (nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search: need nq >= 0 and 1 <= k <= 1024%s");
     if (nq == 0) return SRX_OK;
@@ -1638,11 +1641,11 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), bm_bytes, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
-                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
+                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count, ors, ocs);
     else
         hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), bm_bytes, stream, v, q_ptr, q_term, q_weight,
                            nq, k, p.n_splits, p.tpu, p.n_super, dbg, ovf, p.ovf_words, p.lists_per_q, work,
-                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count);
+                           cand_doc, cand_score, cand_count, ix->d.doc_base, out_doc, out_score, out_count, ors, ocs);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
     // tier 2: flagged units, long queries, k > 128 -- a fixed grid drains the worklist tier 1 filled
@@ -1658,7 +1661,7 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
-                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score, out_count);
+                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score, out_count, ors, ocs);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(ev[3], stream));
@@ -1666,6 +1669,23 @@ SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_ter
         if (ix->ev_n < PROF_SLOTS) ++ix->ev_n;
     }
     return SRX_OK;
+}
+}  // namespace
+
+SRX_API int srx_search(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                       int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                       int64_t workspace_bytes, void *stream_v) {
+    return search_impl(ix, q_ptr, q_term, q_weight, nq, k, out_doc, out_score, out_count, (int64_t)k, (int64_t)1, workspace,
+                       workspace_bytes, stream_v);
+}
+
+SRX_API int srx_search_packed(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight,
+                              int32_t nq, int32_t k, int32_t *out_packed, void *workspace, int64_t workspace_bytes,
+                              void *stream_v) {
+    if (!out_packed || k <= 0) return fail(SRX_ERR_INVALID, "srx_search_packed: bad argument%s");
+    const int64_t row = 2 * (int64_t)k + 1;  // [k doc ids][k score bit patterns][count]
+    return search_impl(ix, q_ptr, q_term, q_weight, nq, k, out_packed, reinterpret_cast<float *>(out_packed + k),
+                       out_packed + 2 * k, row, row, workspace, workspace_bytes, stream_v);
 }
 
 SRX_API int srx_profile_read(srx_index *ix, float *h_ms4) {
@@ -1704,7 +1724,8 @@ SRX_API int64_t srx_merge_workspace_bytes(int32_t nq, int32_t n_lists, int32_t k
 namespace {
 int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count, int32_t nq,
                int32_t n_lists, int32_t k, int lay, int64_t row_stride, int64_t cnt_stride, int32_t *out_doc,
-               float *out_score, int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+               float *out_score, int32_t *out_count, int64_t ors, int64_t ocs, void *workspace, int64_t workspace_bytes,
+               void *stream_v) {
     if (nq < 0 || n_lists <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_merge_topk: bad argument%s");
     if (nq == 0) return SRX_OK;
     if (!in_doc || !in_score || !in_count || !out_doc || !out_score || !out_count)
@@ -1728,7 +1749,7 @@ int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, con
         int32_t *oc = (int32_t *)(os + (int64_t)nq * groups * k);
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cur_doc,
                            cur_score, cur_count, nq, lists, k, fan, groups, 0, lay, row_stride, cnt_stride, (int64_t)0, od, os,
-                           oc);
+                           oc, (int64_t)k, (int64_t)1);
         HIP_TRY(hipGetLastError());
         lay = 0;
         row_stride = k;
@@ -1740,7 +1761,7 @@ int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, con
         ++level;
     }
     hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
-                       lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count);
+                       lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs);
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
@@ -1750,7 +1771,7 @@ SRX_API int srx_merge_topk(int32_t device, const int32_t *in_doc, const float *i
                            int32_t nq, int32_t n_lists, int32_t k, int32_t gathered, int32_t *out_doc, float *out_score,
                            int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
     return merge_impl(device, in_doc, in_score, in_count, nq, n_lists, k, gathered ? 1 : 0, (int64_t)k, (int64_t)1, out_doc,
-                      out_score, out_count, workspace, workspace_bytes, stream_v);
+                      out_score, out_count, (int64_t)k, (int64_t)1, workspace, workspace_bytes, stream_v);
 }
 
 SRX_API int srx_merge_topk_packed(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
@@ -1759,7 +1780,16 @@ SRX_API int srx_merge_topk_packed(int32_t device, const int32_t *packed, int32_t
     if (!packed || k <= 0) return fail(SRX_ERR_INVALID, "srx_merge_topk_packed: bad argument%s");
     const int64_t row = 2 * (int64_t)k + 1;  // [k doc ids][k score bit patterns][count]
     return merge_impl(device, packed, reinterpret_cast<const float *>(packed + k), packed + 2 * k, nq, n_lists, k, 1, row, row,
-                      out_doc, out_score, out_count, workspace, workspace_bytes, stream_v);
+                      out_doc, out_score, out_count, (int64_t)k, (int64_t)1, workspace, workspace_bytes, stream_v);
+}
+
+SRX_API int srx_merge_topk_packed_out(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
+                                      int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (!packed || !out_packed || k <= 0) return fail(SRX_ERR_INVALID, "srx_merge_topk_packed_out: bad argument%s");
+    const int64_t row = 2 * (int64_t)k + 1;
+    return merge_impl(device, packed, reinterpret_cast<const float *>(packed + k), packed + 2 * k, nq, n_lists, k, 1, row, row,
+                      out_packed, reinterpret_cast<float *>(out_packed + k), out_packed + 2 * k, row, row, workspace,
+                      workspace_bytes, stream_v);
 }
 
 SRX_API int srx_build_impacts(int32_t device, const float *tf, const int32_t *post_doc, const float *doc_len,

@@ -66,17 +66,25 @@ class ShardedSearcher:
     torch-tensor functions on one device.  The product wiring is :meth:`for_device_index` (HIP engine:
     ``srx_search`` + ``srx_merge_topk_packed``); tests inject CPU callables to exercise the protocol under gloo."""
 
-    def __init__(self, local_search: Callable, pack: Callable, merge: Callable, group=None):
+    def __init__(self, local_search: Callable, pack: Callable, merge: Callable, group=None,
+                 local_search_packed: Callable = None, merge_packed_out: Callable = None):
         self.local_search = local_search
         self.pack = pack
         self.merge = merge
         self.group = group
         self._buf = None
+        self.mode = "a2a"
+        # Optional in-place variants (no packing / unpacking kernels around the exchange):
+        # local_search_packed(q_ptr, q_term, q_weight, k, out i32[nq, 2k+1]) and
+        # merge_packed_out(packed i32[W, nq, 2k+1], k, out i32[nq, 2k+1]) fill `out` rows [k docs][k score bits][count].
+        self.local_search_packed = local_search_packed
+        self.merge_packed_out = merge_packed_out
 
     @classmethod
     def for_device_index(cls, index, group=None) -> "ShardedSearcher":
-        from .index import merge_topk_packed_device, pack_results
-        return cls(index.search_device, pack_results, merge_topk_packed_device, group)
+        from .index import merge_topk_packed_device, merge_topk_packed_out_device, pack_results
+        return cls(index.search_device, pack_results, merge_topk_packed_device, group,
+                   local_search_packed=index.search_packed_device, merge_packed_out=merge_topk_packed_out_device)
 
     def search(self, q_ptr, q_term, q_weight, k: int, chunks: int = 0, q_ptr_host=None):
         """One batch.  Optionally (chunks > 1) the batch is cut into sub-batches: the all-gather + merge of
@@ -92,6 +100,8 @@ class ShardedSearcher:
         on_gpu = q_ptr.is_cuda
         if chunks <= 0:
             chunks = 1  # measured on one GPU: cutting the batch costs more (under-filled launches) than it can hide
+        if (chunks == 1 or not on_gpu) and self.local_search_packed is not None and self.merge_packed_out is not None:
+            return self._search_packed(q_ptr, q_term, q_weight, k, world)
         if chunks == 1 or not on_gpu:
             doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
             return self._exchange(doc, score, count, k, world, slot=0)
@@ -123,6 +133,89 @@ class ShardedSearcher:
                 t.record_stream(main)
         return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
 
+    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int):
+        """The exchange of :meth:`_exchange` on packed rows end to end: the local search writes packed rows straight
+        into the send buffer, the merge reads the received rows in place and writes packed rows, and the results are
+        views of the gathered buffer (doc = rows[:, :k], score = rows[:, k:2k] as f32, count = rows[:, 2k]).
+
+        With ``self.overlap`` (GPU only) the exchange + merge run on a second HIP stream, so that they overlap the
+        scoring of the NEXT batch submitted to the main stream (send / receive buffers are double-buffered and guarded
+        by events).  The returned tensors are then complete once :meth:`wait` (or a device synchronize) has run."""
+        import torch
+        import torch.distributed as dist
+        nq = q_ptr.shape[0] - 1
+        row = 2 * k + 1
+        dev = q_ptr.device
+        if self._buf is None:
+            self._buf = {}
+        overlap = bool(getattr(self, "overlap", False)) and q_ptr.is_cuda
+        slot = 0
+        if overlap:
+            self._step = getattr(self, "_step", 0) + 1
+            slot = self._step & 1
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+                self._slot_ev = {}
+            side = self._side
+            ev_prev = self._slot_ev.get(slot)
+            if ev_prev is not None:
+                main.wait_event(ev_prev)  # the exchange that last used this slot's buffers has finished
+
+        def exchange(mine, send, recv):
+            if self.mode == "allgather":
+                dist.all_gather_into_tensor(recv.view(world * nq, row), mine, group=self.group)
+                out = torch.empty((nq, row), dtype=torch.int32, device=dev)
+                self.merge_packed_out(recv, k, out)
+                return out
+            blk = recv.shape[1]
+            dist.all_to_all_single(recv.view(world * blk, row), send, group=self.group)
+            merged = torch.empty((blk, row), dtype=torch.int32, device=dev)
+            self.merge_packed_out(recv, k, merged)
+            allrows = torch.empty((world * blk, row), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(allrows, merged, group=self.group)
+            return allrows[:nq]
+
+        if self.mode == "allgather":
+            key = ("pag", world, nq, k, dev, slot)
+            bufs = self._buf.get(key)
+            if bufs is None:
+                bufs = self._buf[key] = (torch.empty((nq, row), dtype=torch.int32, device=dev),
+                                         torch.empty((world, nq, row), dtype=torch.int32, device=dev))
+            mine, recv = bufs
+            send = mine
+            self.local_search_packed(q_ptr, q_term, q_weight, k, mine)
+        else:
+            blk = (nq + world - 1) // world
+            key = ("pa2a", world, nq, k, dev, slot)
+            bufs = self._buf.get(key)
+            if bufs is None:
+                bufs = self._buf[key] = (torch.zeros((world * blk, row), dtype=torch.int32, device=dev),  # send; rows >= nq stay empty
+                                         torch.empty((world, blk, row), dtype=torch.int32, device=dev))   # the lists of my query block
+            send, recv = bufs
+            mine = send[:nq]
+            self.local_search_packed(q_ptr, q_term, q_weight, k, mine)
+        if not overlap:
+            out = exchange(mine, send, recv)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                out = exchange(mine, send, recv)
+                done = torch.cuda.Event()
+                done.record(side)
+            self._slot_ev[slot] = done
+            out.record_stream(main)  # allocated on the side stream, consumed by the caller on the main stream
+        return out[:, :k], out[:, k:2 * k].view(torch.float32), out[:, 2 * k]
+
+    def wait(self) -> None:
+        """Make the current stream wait for every exchange submitted with ``overlap`` (no-op otherwise)."""
+        side = getattr(self, "_side", None)
+        if side is not None:
+            import torch
+            torch.cuda.current_stream(side.device).wait_stream(side)
+
     def _exchange(self, doc, score, count, k: int, world: int, slot: int):
         """Per-shard top-k -> global top-k.
 
@@ -137,7 +230,7 @@ class ShardedSearcher:
         mine = self.pack(doc, score, count)  # [nq, 2k+1] i32: nq*(8k+4) bytes per rank
         if self._buf is None:
             self._buf = {}
-        mode = getattr(self, "mode", "a2a")
+        mode = self.mode
         if mode == "allgather":
             key = ("ag", world, nq, k, mine.device, slot)
             g = self._buf.get(key)

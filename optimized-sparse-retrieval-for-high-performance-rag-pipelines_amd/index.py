@@ -305,6 +305,26 @@ class DeviceIndex:
             _capi.check(rc, "srx_search")
         return out
 
+    def search_packed_device(self, q_ptr, q_term, q_weight, k: int, out=None):
+        """``srx_search_packed``: the same search, each query's result written as one row
+        [k doc ids][k score bit patterns][count] of ``out`` (i32[nq, 2k+1], contiguous) -- the exchange format of the
+        sharded search, so no packing kernel runs.  Returns ``out``."""
+        torch = _torch()
+        nq = q_ptr.numel() - 1
+        if not (1 <= k <= _capi.limits()["max_k"]):
+            raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((nq, 2 * k + 1), dtype=torch.int32, device=self.device)
+            assert out.dtype == torch.int32 and tuple(out.shape) == (nq, 2 * k + 1) and out.is_contiguous()
+            need = self.workspace_bytes(nq, k)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            rc = _capi.lib().srx_search_packed(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out),
+                                               _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+            _capi.check(rc, "srx_search_packed")
+        return out
+
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
         """Host arrays in, host arrays out (doc, score, count)."""
         torch = _torch()
@@ -371,6 +391,25 @@ def pack_results(doc, score, count):
     out[:, :k] = doc
     out[:, k:2 * k] = score.view(torch.int32)
     out[:, 2 * k] = count
+    return out
+
+
+def merge_topk_packed_out_device(packed, k: int, out=None):
+    """``srx_merge_topk_packed_out``: gathered packed rows [n_lists, nq, 2k+1] -> packed rows ``out`` [nq, 2k+1]."""
+    torch = _torch()
+    n_lists, nq, row = packed.shape
+    assert row == 2 * k + 1 and packed.dtype == torch.int32 and packed.is_contiguous()
+    dev = packed.device
+    L = _capi.lib()
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty((nq, row), dtype=torch.int32, device=dev)
+        assert out.dtype == torch.int32 and tuple(out.shape) == (nq, row) and out.is_contiguous()
+        need = _capi.check(L.srx_merge_workspace_bytes(nq, n_lists, k), "srx_merge_workspace_bytes")
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        rc = L.srx_merge_topk_packed_out(dev.index or 0, _ptr(packed), nq, n_lists, k, _ptr(out), _ptr(ws), ws.numel(),
+                                         _stream_ptr(torch, dev))
+        _capi.check(rc, "srx_merge_topk_packed_out")
     return out
 
 

@@ -84,8 +84,20 @@ def _worker(rank, world, port, mode, ret):
         d = np.where(d >= 0, d + a, -1).astype(np.int32)  # doc_base
         return torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(n)
 
-    searcher = sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed)
-    searcher.mode = mode
+    if mode.endswith("+packed"):  # the in-place variants the HIP wiring uses (srx_search_packed / srx_merge_topk_packed_out)
+        def local_search_packed(q_ptr, q_term, q_w, kk, out):
+            out.copy_(_pack(*local_search(q_ptr, q_term, q_w, kk)))
+            return out
+
+        def merge_packed_out(packed, kk, out):
+            out.copy_(_pack(*_merge_packed(packed, kk)))
+            return out
+
+        searcher = sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed, local_search_packed=local_search_packed,
+                                             merge_packed_out=merge_packed_out)
+    else:
+        searcher = sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed)
+    searcher.mode = mode.split("+")[0]
     d, s, n = searcher.search(*(torch.from_numpy(x) for x in q), k)
     ed, es, en = oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf_ref, q[0], q[1], q[2], k, 1.2, 0.75, avgdl_ref)
     ok = (np.array_equal(n.numpy(), en) and np.array_equal(d.numpy(), ed)
@@ -94,7 +106,8 @@ def _worker(rank, world, port, mode, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "a2a"), (3, "a2a"), (2, "allgather"), (3, "allgather")])
+@pytest.mark.parametrize("world,mode", [(2, "a2a"), (3, "a2a"), (2, "allgather"), (3, "allgather"), (2, "a2a+packed"),
+                                        (3, "a2a+packed"), (3, "allgather+packed")])
 def test_sharded_search_matches_single_shard(world, mode):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:

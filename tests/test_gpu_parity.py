@@ -265,6 +265,22 @@ def test_merge_topk_matches_single_shard(rx):
         d, s, n = merge_topk_packed_device(packed, k)
         torch.cuda.synchronize()
         _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), exp, f"packed shards={shards}")
+        # packed rows out as well (srx_merge_topk_packed_out)
+        from sparse_rx.index import merge_topk_packed_out_device
+        rows = merge_topk_packed_out_device(packed, k)
+        torch.cuda.synchronize()
+        _assert_exact((rows[:, :k].cpu().numpy(), rows[:, k:2 * k].contiguous().view(torch.float32).cpu().numpy(),
+                       rows[:, 2 * k].cpu().numpy()), exp, f"packed-out shards={shards}")
+    # srx_search_packed == srx_search, row by row (one split and several splits per query)
+    for nq_sub in (len(q[0]) - 1, 3):
+        qs = (q[0][: nq_sub + 1], q[1][: q[0][nq_sub]], q[2][: q[0][nq_sub]])
+        ix = _dev_index(rx, c, idf, avgdl, tile_log2=10)
+        qd = [torch.as_tensor(x, device="cuda:0") for x in qs]
+        d, s, n = ix.search_device(*qd, k)
+        rows = ix.search_packed_device(*qd, k)
+        torch.cuda.synchronize()
+        assert torch.equal(rows[:, :k], d) and torch.equal(rows[:, k:2 * k], s.view(torch.int32)) and torch.equal(rows[:, 2 * k], n)
+        ix.close()
 
 
 def test_impacts_bit_exact(rx):
