@@ -80,7 +80,11 @@ constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
 constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
-constexpr int W_R = 12;                     // postings per lane per unit held in registers (steps)
+#ifndef SRX_W_R
+#define SRX_W_R 12
+#endif
+constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8 or 12)
+constexpr int W_WAVES_PER_EU = W_R <= 8 ? 4 : 3;  // what the register budget of that choice allows
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_DUPCAP = 48;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
 constexpr int W_LCAP = 384;                 // lazy top-k list capacity (entries; a multiple of 64)
@@ -820,15 +824,18 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct WaveShared {
-    unsigned lbits[W_LCAP];        // lazy top-k list; doubles as the radix histogram while a selection holds it in registers
+    unsigned lbits[W_LCAP];        // lazy top-k list (score bits, doc), unordered
     int ldoc[W_LCAP];
+    unsigned hist[256];            // radix histogram of the list selection
 };
 
-// Exact k-th largest of the wave's keys (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix, 256-bin LDS
-// histogram, 4 bins per lane.  Requires 1 <= k <= #candidates.
-template <int N>
-__device__ unsigned wave_radix_kth(const unsigned (&key)[N], unsigned k, unsigned mx, unsigned mn, unsigned n_cand,
-                                   unsigned *hist, unsigned *n_gt, unsigned *n_eq) {
+// Exact k-th largest of the keys keyfn(i), i < count (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix with a
+// 256-bin LDS histogram, 4 bins per lane.  The keys are re-read from LDS in every pass (a loop, not registers): the
+// selection is rare, and a small register footprint here is what keeps the calling kernel's VGPR count low (the
+// caller's live values must sit above the callee's registers).  Requires 1 <= k <= #candidates.
+template <typename KeyFn>
+__device__ __forceinline__ unsigned wave_radix_kth(KeyFn keyfn, unsigned count, unsigned k, unsigned mx, unsigned mn,
+                                                   unsigned n_cand, unsigned *hist, unsigned *n_gt, unsigned *n_eq) {
     if (mx == mn) {
         *n_gt = 0;
         *n_eq = n_cand;
@@ -845,9 +852,8 @@ __device__ unsigned wave_radix_kth(const unsigned (&key)[N], unsigned k, unsigne
         const int hi_shift = shift + w;
         reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
         wsync();
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const unsigned x = key[n];
+        for (unsigned i = lane; i < count; i += 64) {
+            const unsigned x = keyfn(i);
             if (x != 0 && ((x ^ prefix) >> hi_shift) == 0) atomicAdd(&hist[(x >> shift) & ((1u << w) - 1u)], 1u);
         }
         wsync();
@@ -891,61 +897,56 @@ __device__ unsigned wave_radix_kth(const unsigned (&key)[N], unsigned k, unsigne
 }
 
 // Shrink the wave's list (count > k entries in LDS) to its exact top k; returns tau = key of the k-th.
+// Ties at the k-th score keep the smallest doc ids (the order contract).  Works in place on the LDS list.
 __device__ __noinline__ unsigned wave_list_select(WaveShared &S, unsigned count, int k) {
-    constexpr int LPT = W_LCAP / 64;  // list entries per lane
     const int lane = threadIdx.x;
-    unsigned key[LPT];
-    int doc[LPT];
     unsigned mx = 0, mn = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-        const unsigned i = lane + 64 * j;
-        const bool ok = i < count;
-        key[j] = ok ? S.lbits[i] : 0u;
-        doc[j] = ok ? S.ldoc[i] : 0;
-        if (ok) {
-            mx = max(mx, key[j]);
-            mn = min(mn, key[j]);
-        }
+    for (unsigned i = lane; i < count; i += 64) {
+        const unsigned x = S.lbits[i];
+        mx = max(mx, x);
+        mn = min(mn, x);
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
-    wsync();  // the list is in registers now: its LDS (lbits) serves as the histogram
     unsigned n_gt, n_eq;
-    const unsigned T = wave_radix_kth<LPT>(key, (unsigned)k, mx, mn, count, S.lbits, &n_gt, &n_eq);
+    const unsigned T = wave_radix_kth([&](unsigned i) -> unsigned { return S.lbits[i]; }, count, (unsigned)k, mx, mn, count,
+                                      S.hist, &n_gt, &n_eq);
     const unsigned need = (unsigned)k - n_gt;
     unsigned T2 = 0;
-    if (n_eq > need) {  // uniform
-        unsigned key2[LPT];
+    if (n_eq > need) {  // uniform: more entries tie at T than fit -> the `need` smallest doc ids among them
+        auto key2 = [&](unsigned i) -> unsigned { return S.lbits[i] == T ? 0x7FFFFFFFu - (unsigned)S.ldoc[i] : 0u; };
         unsigned mx2 = 0, mn2 = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            key2[j] = (key[j] == T) ? (0x7FFFFFFFu - (unsigned)doc[j]) : 0u;
-            if (key2[j] != 0) {
-                mx2 = max(mx2, key2[j]);
-                mn2 = min(mn2, key2[j]);
+        for (unsigned i = lane; i < count; i += 64) {
+            const unsigned x = key2(i);
+            if (x != 0) {
+                mx2 = max(mx2, x);
+                mn2 = min(mn2, x);
             }
         }
         mx2 = wave_max(mx2);
         mn2 = wave_min(mn2);
         unsigned g2, e2;
-        T2 = wave_radix_kth<LPT>(key2, need, mx2, mn2, n_eq, S.lbits, &g2, &e2);
+        T2 = wave_radix_kth(key2, count, need, mx2, mn2, n_eq, S.hist, &g2, &e2);
     }
     wsync();
-    unsigned base = 0;  // deterministic compaction (ballot prefix), wave-uniform running count
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-        const unsigned x = key[j];
-        const bool take = x != 0 && ((x > T) || (x == T && (0x7FFFFFFFu - (unsigned)doc[j]) >= T2));
+    // Deterministic in-place compaction: 64 entries per step are read before any is written, and an entry only moves
+    // down (its new position <= the number of entries read so far).
+    unsigned base = 0;  // wave-uniform running count
+    for (unsigned i0 = 0; i0 < count; i0 += 64) {
+        const unsigned i = i0 + lane;
+        const unsigned x = i < count ? S.lbits[i] : 0u;
+        const int dd = i < count ? S.ldoc[i] : 0;
+        const bool take = x != 0 && ((x > T) || (x == T && (0x7FFFFFFFu - (unsigned)dd) >= T2));
         const unsigned long long m = __ballot(take);
+        wsync();
         if (take) {
             const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
             S.lbits[p] = x;
-            S.ldoc[p] = doc[j];
+            S.ldoc[p] = dd;
         }
         base += (unsigned)__popcll(m);
+        wsync();
     }
-    wsync();
     return T;
 }
 
@@ -979,7 +980,7 @@ struct IntC {
 };
 
 template <typename VT>
-__global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_EU))) void srx_wave_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                       const int32_t *__restrict__ q_term,
                                                       const float *__restrict__ q_weight, int nq, int k, int n_splits,
                                                       int tpu, int n_super, int dbg,
@@ -1224,12 +1225,19 @@ __global__ __launch_bounds__(64) void srx_wave_kernel(IndexView ix, const int32_
                 flag_tier2(su);
             } else if (__ballot(lenc > 0) != 0ull) {
                 bool fine;
-                if (__ballot(lenc - 4 * jl > 8 * LPT) != 0ull)  // uniform: the third load step holds postings
-                    fine = process(IntC<12>{}, su, lenc, d, v);
-                else if (__ballot(lenc - 4 * jl > 4 * LPT) != 0ull)
-                    fine = process(IntC<8>{}, su, lenc, d, v);
-                else
-                    fine = process(IntC<4>{}, su, lenc, d, v);
+                bool done = false;
+                if constexpr (W_R > 8) {
+                    if (__ballot(lenc - 4 * jl > 8 * LPT) != 0ull) {  // uniform: the third load step holds postings
+                        fine = process(IntC<W_R>{}, su, lenc, d, v);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    if (__ballot(lenc - 4 * jl > 4 * LPT) != 0ull)
+                        fine = process(IntC<8>{}, su, lenc, d, v);
+                    else
+                        fine = process(IntC<4>{}, su, lenc, d, v);
+                }
                 if (!fine) flag_tier2(su);
             }
             b1 = b2;
