@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="N > 1: how per-shard top-k lists meet")
+    ap.add_argument("--local-bounds", action="store_true", help="N > 1: keep per-shard score bounds (no corpus-wide bound exchange)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="dev: on one GPU, use the score bounds a shard would get among this many identical shards")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--force-dist", action="store_true",
@@ -155,6 +157,15 @@ def main():
     torch.cuda.empty_cache()
     ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,
                 unit_tiles=args.unit_tiles)
+    if world > 1 and not args.local_bounds:
+        # corpus-wide score bounds (one all-gather of a few MB at start-up): every shard starts from the single-GPU
+        # threshold instead of its own shard's; exact
+        sparse_rx.global_term_bounds(ix)
+    elif args.emulate_world > 1 and ix.fine_bound is not None:
+        # dev rehearsal on one GPU: the bounds this shard would get among `emulate_world` statistically identical shards
+        # (its rows are then NOT its own full top-k: use with --no-cpu-baseline)
+        from sparse_rx.index import combine_term_bounds
+        ix.set_term_bound(combine_term_bounds(ix.fine_bound.unsqueeze(0).expand(args.emulate_world, -1, -1), args.emulate_world))
     build_s = time.perf_counter() - t_build
 
     # ---- query batch, resident in HBM before the timed region --------------------------------------------------

@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
 #pragma unroll
                 for (int r = 1; r + 1 < NR; r += 2) vmax = fmaxf(fmaxf(vmax, v[r]), v[r + 1]);
                 if constexpr (NR % 2 == 0) vmax = fmaxf(vmax, v[NR - 1]);
-                if (__ballot(vmax >= vthr) != 0ull) {  // uniform, rare after warm-up
+                if (__ballot(vmax >= vthr) != 0ull && !(dbg & 64)) {  // uniform, rare after warm-up (debug 64: timing experiment, screening only)
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const bool pass = v[r] >= vthr;
@@ -1259,6 +1259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
     }
     if ((dbg & 4) && sink == 0x7F123457) cand_count[list] = sink;  // keeps the loads of the timing experiment alive
     unsigned count = tk.count;
+    if (dbg & 32) count = 0;  // timing experiment: no final selection / ranking
     if (count > (unsigned)k) {
         wave_list_select(S, count, k);
         count = (unsigned)k;

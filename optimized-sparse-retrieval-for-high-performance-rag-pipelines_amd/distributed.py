@@ -52,6 +52,24 @@ def global_avgdl(doc_lengths_local, n_docs_total: int, group=None) -> float:
     return float(np.mean(torch.cat(parts).cpu().numpy().astype(np.float32)))
 
 
+def global_term_bounds(index, group=None) -> None:
+    """Install corpus-wide score bounds on this rank's DeviceIndex: all-gather the shards' fine bound tables (a few MB,
+    once, at start-up) and combine them (index.combine_term_bounds).  The search stays exact -- the bounds only have
+    to be LOWER bounds of the corpus-wide k-th best score -- but every shard now starts from (nearly) the single-GPU
+    threshold instead of its own shard's, so it appends ~1/W of the candidates during warm-up; a shard may then
+    return fewer than k rows, which is all the final merge can use."""
+    import torch
+    import torch.distributed as dist
+    from .index import combine_term_bounds
+    if index.fine_bound is None or not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    world = dist.get_world_size(group)
+    mine = index.fine_bound.contiguous()
+    g = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(g.view(world * mine.shape[0], mine.shape[1]), mine, group=group)
+    index.set_term_bound(combine_term_bounds(g, world))
+
+
 def bm25_idf_from_df(df_global, n_docs_total: int) -> np.ndarray:
     """retrieval.py:187-189 on the corpus-wide df (f64 log, cast to f32)."""
     df = df_global.detach().cpu().numpy() if hasattr(df_global, "detach") else np.asarray(df_global)

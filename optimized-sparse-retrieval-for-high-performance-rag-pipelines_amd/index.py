@@ -141,11 +141,12 @@ class DeviceIndex:
     keeps pointers."""
 
     def __init__(self, term_ptr, post_doc, post_val, tile_skip, idf, n_docs: int, vocab: int, doc_base: int,
-                 tile_log2: int, device, term_bound=None):
+                 tile_log2: int, device, term_bound=None, fine_bound=None):
         torch = _torch()
         self.device = torch.device(device)
         self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf = term_ptr, post_doc, post_val, tile_skip, idf
         self.term_bound = term_bound
+        self.fine_bound = fine_bound  # [V, len(FINE_KS)]: the same statistic at more ranks K (sharded deployments combine these)
         self.n_docs, self.vocab, self.doc_base, self.tile_log2 = int(n_docs), int(vocab), int(doc_base), int(tile_log2)
         self.n_tiles = (self.n_docs + (1 << tile_log2) - 1) >> tile_log2
         self.nnz = int(post_doc.numel()) - POST_PAD
@@ -159,6 +160,26 @@ class DeviceIndex:
         self._h = h
         self._ws = None
         self._opts = _capi.SearchOpts()
+
+    def set_term_bound(self, table) -> None:
+        """Replace the score-bound table (f32[V, 4], K = 1, 10, 100, 1000).  Any table of valid LOWER bounds of the K-th
+        largest stored value of each term keeps the search exact; a sharded deployment installs corpus-wide bounds
+        (distributed.global_term_bounds), which spares every shard most of its threshold warm-up."""
+        torch = _torch()
+        if table is not None:
+            table = table.to(device=self.device, dtype=torch.float32).contiguous()
+            assert tuple(table.shape) == (self.vocab, len(self.BOUND_KS))
+        torch.cuda.synchronize(self.device)
+        self.term_bound = table
+        d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
+                            nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
+                            term_ptr=_ptr(self.term_ptr), post_doc=_ptr(self.post_doc), post_val=_ptr(self.post_val),
+                            tile_skip=_ptr(self.tile_skip), idf=_ptr(self.idf), term_bound=_ptr(table))
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
+        _capi.lib().srx_index_destroy(self._h)
+        self._h = h
+        _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
 
     # -- construction ----------------------------------------------------------------------------------
     @classmethod
@@ -234,7 +255,8 @@ class DeviceIndex:
                 post_val = tf.to(torch.float16) if val_dtype == "f16" else tf
             else:
                 raise ValueError(f"unknown mode {mode!r}")
-            term_bound = cls._term_bounds(torch, cols_sorted, post_val, term_ptr, df, V) if score_bounds else None
+            fine_bound = cls._term_bounds(torch, cols_sorted, post_val, term_ptr, df, V) if score_bounds else None
+            term_bound = None if fine_bound is None else fine_bound[:, [cls.FINE_KS.index(K) for K in cls.BOUND_KS]].contiguous()
             del cols_sorted
             # SRX_POST_PAD: the kernels read 4 postings per load and may run past the end of the last list
             post_doc = torch.cat([post_doc, torch.zeros(POST_PAD, dtype=post_doc.dtype, device=dev)])[:nnz + POST_PAD]
@@ -244,14 +266,16 @@ class DeviceIndex:
             _capi.check(L.srx_build_tile_skip(dev.index or 0, _ptr(term_ptr), _ptr(post_doc), V, n_tiles, tile_log2,
                                               _ptr(tile_skip), stream), "srx_build_tile_skip")
             torch.cuda.synchronize(dev)
-        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, term_bound=term_bound)
+        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, term_bound=term_bound,
+                   fine_bound=fine_bound)
 
-    BOUND_KS = (1, 10, 100, 1000)
+    BOUND_KS = (1, 10, 100, 1000)  # the ranks K the engine looks up (include/sparse_rx.h: term_bound[vocab*4])
+    FINE_KS = (1, 2, 4, 8, 10, 16, 32, 64, 100, 128, 256, 512, 1000, 1024)  # ... and the ranks kept for combining shards
 
     @staticmethod
     def _term_bounds(torch, cols_sorted, post_val, term_ptr, df, V):
-        """term_bound[t, j] = the K_j-th largest stored value of term t (0 if it has fewer than K_j postings), or None
-        when some value is negative.  One sort of (term, value descending) keys; exact."""
+        """out[t, j] = the K_j-th largest stored value of term t for K_j in FINE_KS (0 if it has fewer than K_j
+        postings), or None when some value is negative.  One sort of (term, value descending) keys; exact."""
         nnz = post_val.numel()
         if nnz == 0 or cols_sorted is None:
             return None
@@ -262,8 +286,8 @@ class DeviceIndex:
         key = (cols_sorted.to(torch.int64) << 32) | (0xFFFFFFFF - bits)
         del bits, v32
         key = torch.sort(key).values
-        out = torch.zeros((V, len(DeviceIndex.BOUND_KS)), dtype=torch.float32, device=post_val.device)
-        for j, K in enumerate(DeviceIndex.BOUND_KS):
+        out = torch.zeros((V, len(DeviceIndex.FINE_KS)), dtype=torch.float32, device=post_val.device)
+        for j, K in enumerate(DeviceIndex.FINE_KS):
             has = df >= K
             pos = (term_ptr[:-1] + (K - 1)).clamp(max=nnz - 1)
             b = (0xFFFFFFFF - (key[pos] & 0xFFFFFFFF)).to(torch.int32).view(torch.float32)
@@ -274,6 +298,49 @@ class DeviceIndex:
     def from_host_index(cls, hi: HostIndex, k1: float = 1.2, b: float = 0.75, **kw) -> "DeviceIndex":
         return cls.from_csr(hi.indptr, hi.indices, hi.data, hi.idf, doc_lengths=hi.doc_lengths, k1=k1, b=b,
                             avgdl=hi.avgdl, **kw)
+
+    # -- native shard file -------------------------------------------------------------
+    def save(self, path: str) -> None:
+        """Write this shard (postings, skip table, idf, bounds) to a native shard file (shardfile.py)."""
+        from . import shardfile
+        torch = _torch()
+        torch.cuda.synchronize(self.device)
+        arrays = {n: getattr(self, n).cpu().numpy() for n in ("term_ptr", "post_doc", "post_val", "tile_skip", "idf")}
+        if self.term_bound is not None:
+            arrays["term_bound"] = self.term_bound.cpu().numpy().reshape(-1)
+        if self.fine_bound is not None:
+            arrays["fine_bound"] = self.fine_bound.cpu().numpy().reshape(-1)
+        shardfile.write_shard_file(path, arrays, {"n_docs": self.n_docs, "vocab": self.vocab, "nnz": self.nnz,
+                                                  "doc_base": self.doc_base, "tile_log2": self.tile_log2,
+                                                  "post_pad": POST_PAD})
+
+    @classmethod
+    def load(cls, path: str, device="cuda:0", doc_base=None, verify: bool = True, chunk_bytes: int = 1 << 28) -> "DeviceIndex":
+        """Read a native shard file: memory-map it and stream every array to the GPU in chunks."""
+        from . import shardfile
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.SparseRxUnavailable("no HIP device visible: DeviceIndex needs a GPU (there is no CPU fallback)")
+        meta, arr = shardfile.read_shard_file(path, verify=verify)
+        if int(meta.get("post_pad", 0)) < POST_PAD:
+            raise ValueError(f"{path}: written with post_pad {meta.get('post_pad')}, this build needs {POST_PAD}")
+        dev = torch.device(device)
+
+        def up(a):
+            t = torch.empty(a.shape[0], dtype=getattr(torch, a.dtype.name), device=dev)
+            step = max(1, chunk_bytes // max(a.dtype.itemsize, 1))
+            for i in range(0, a.shape[0], step):
+                t[i: i + step].copy_(torch.from_numpy(np.ascontiguousarray(a[i: i + step])))
+            return t
+
+        with torch.cuda.device(dev):
+            tb = up(arr["term_bound"]).view(-1, len(cls.BOUND_KS)) if "term_bound" in arr else None
+            fb = None
+            if "fine_bound" in arr and arr["fine_bound"].shape[0] == int(meta["vocab"]) * len(cls.FINE_KS):
+                fb = up(arr["fine_bound"]).view(-1, len(cls.FINE_KS))
+            return cls(up(arr["term_ptr"]), up(arr["post_doc"]), up(arr["post_val"]), up(arr["tile_skip"]), up(arr["idf"]),
+                       int(meta["n_docs"]), int(meta["vocab"]), int(meta["doc_base"] if doc_base is None else doc_base),
+                       int(meta["tile_log2"]), dev, term_bound=tb, fine_bound=fb)
 
     # -- search ----------------------------------------------------------------------------------------
     def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0,
@@ -381,6 +448,31 @@ def merge_topk_device(in_doc, in_score, in_count, k: int, gathered: bool = False
                               _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream_ptr(torch, dev))
         _capi.check(rc, "srx_merge_topk")
     return out
+
+
+def combine_term_bounds(fine_tables, world: int = None):
+    """Corpus-wide score bounds from the shards' tables.  ``fine_tables``: tensor [W, V, len(FINE_KS)] (or a list of
+    [V, F] tensors), shard r's K-th largest stored value per term for K in DeviceIndex.FINE_KS (0 = fewer than K
+    postings).  Returns f32[V, 4] for K in BOUND_KS, each entry a valid LOWER bound of the K-th largest value of the
+    term over the whole corpus (docs are disjoint across shards and unique inside a term):
+
+      * max over shards of the shard's own K-th largest (K postings >= it exist in that shard alone), and
+      * min over shards of the K'-th largest with K' = the smallest kept rank >= ceil(K / W): every shard then holds
+        K' postings >= that value, W * K' >= K in total.
+
+    On statistically similar shards the second is close to the true corpus-wide K-th largest value."""
+    torch = _torch()
+    t = torch.stack(list(fine_tables)) if isinstance(fine_tables, (list, tuple)) else fine_tables
+    W = t.shape[0] if world is None else world
+    assert t.shape[0] == W and t.shape[2] == len(DeviceIndex.FINE_KS)
+    cols = []
+    for K in DeviceIndex.BOUND_KS:
+        own = t[:, :, DeviceIndex.FINE_KS.index(K)].max(dim=0).values
+        need = -(-K // W)
+        Kp = next(k for k in DeviceIndex.FINE_KS if k >= need)
+        shared = t[:, :, DeviceIndex.FINE_KS.index(Kp)].min(dim=0).values  # 0 as soon as one shard has fewer than K' postings
+        cols.append(torch.maximum(own, shared))
+    return torch.stack(cols, dim=1).contiguous()
 
 
 def pack_results(doc, score, count):

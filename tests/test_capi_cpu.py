@@ -113,3 +113,40 @@ def test_npz_cache_schema_roundtrip(golden_dir, tmp_path):
     assert h2.doc_ids == h.doc_ids and h2.vocabulary == h.vocabulary
     assert np.array_equal(h2.data, h.data) and np.array_equal(h2.indices, h.indices) and np.array_equal(h2.indptr, h.indptr)
     assert np.array_equal(h2.idf.view(np.uint32), h.idf.view(np.uint32)) and h2.avgdl == np.float32(h.avgdl)
+
+
+def test_shard_file_roundtrip_and_corruption(tmp_path):
+    """Native shard file: header + aligned raw arrays; roundtrip is bit-exact, corruption is detected."""
+    from sparse_rx import shardfile
+    rng = np.random.default_rng(3)
+    V, nnz, n_tiles = 37, 1000, 3
+    arrays = {"term_ptr": np.sort(rng.integers(0, nnz, V + 1)).astype(np.int64),
+              "post_doc": rng.integers(0, 5000, nnz + 16).astype(np.int32),
+              "post_val": rng.random(nnz + 16).astype(np.float16),
+              "tile_skip": rng.integers(0, 99, V * (n_tiles + 1)).astype(np.int32),
+              "idf": rng.random(V).astype(np.float32),
+              "term_bound": rng.random(V * 4).astype(np.float32)}
+    meta = {"n_docs": 5000, "vocab": V, "nnz": nnz, "doc_base": 123456789012, "tile_log2": 11, "post_pad": 16}
+    p = str(tmp_path / "shard0.srx")
+    shardfile.write_shard_file(p, arrays, meta)
+    m2, a2 = shardfile.read_shard_file(p)
+    assert m2 == meta
+    assert set(a2) == set(arrays)
+    for k in arrays:
+        assert a2[k].dtype == arrays[k].dtype and np.array_equal(np.asarray(a2[k]).view(np.uint8), arrays[k].view(np.uint8)), k
+    # optional array absent
+    del arrays["term_bound"]
+    shardfile.write_shard_file(p, arrays, meta)
+    assert "term_bound" not in shardfile.read_shard_file(p)[1]
+    # flip one payload byte -> checksum mismatch; truncate -> error; wrong magic -> error
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) - 4096 + 10] ^= 0x40  # inside the last array (idf), whose padded block ends the file
+    open(p, "wb").write(raw)
+    with pytest.raises(ValueError, match="checksum"):
+        shardfile.read_shard_file(p)
+    open(p, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        shardfile.read_shard_file(p)
+    open(p, "wb").write(b"NOTSHARD" + bytes(100))
+    with pytest.raises(ValueError, match="not a sparse-rx shard file"):
+        shardfile.read_shard_file(p)

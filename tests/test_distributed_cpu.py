@@ -129,3 +129,30 @@ def test_shard_range_partitions():
             rs = [sparse_rx.shard_range(n, w, r) for r in range(w)]
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+
+
+def test_combined_term_bounds_are_lower_bounds():
+    """combine_term_bounds: for every term and K, the combined value is <= the corpus-wide K-th largest stored value
+    (so it is a valid initial threshold on every shard), and on similar shards it beats the per-shard bound."""
+    from sparse_rx.index import DeviceIndex, combine_term_bounds
+    rng = np.random.default_rng(8)
+    V, W = 40, 4
+    shards = [[np.sort(rng.random(rng.integers(0, 40) if t < 5 else rng.integers(1500, 3000)).astype(np.float32))[::-1]
+               for t in range(V)] for _ in range(W)]  # terms 0-4 are rare (missing ranks), the others similar across shards
+    fine = torch.zeros((W, V, len(DeviceIndex.FINE_KS)))
+    for r in range(W):
+        for t in range(V):
+            for j, K in enumerate(DeviceIndex.FINE_KS):
+                if len(shards[r][t]) >= K:
+                    fine[r, t, j] = float(shards[r][t][K - 1])
+    comb = combine_term_bounds(fine, W).numpy()
+    better = 0
+    for t in range(V):
+        allv = np.sort(np.concatenate([shards[r][t] for r in range(W)]))[::-1]
+        for j, K in enumerate(DeviceIndex.BOUND_KS):
+            true_k = allv[K - 1] if len(allv) >= K else 0.0
+            assert comb[t, j] <= true_k, (t, K, comb[t, j], true_k)
+            own = max(float(fine[r, t, DeviceIndex.FINE_KS.index(K)]) for r in range(W))
+            assert comb[t, j] >= own
+            better += comb[t, j] > own
+    assert better >= 2 * (V - 5)  # the shared bound is the stronger one for K = 10, 100, 1000 on similar shards

@@ -400,3 +400,67 @@ def test_fuzz_shapes_vs_oracle(rx):
             _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k),
                           f"fuzz trial={trial} docs={n_docs} V={vocab} draws={draws} s={s} terms={terms} tile={tile_log2} ut={ut} k={k}")
         ix.close()
+
+
+def test_shard_file_save_load(rx, tmp_path):
+    """DeviceIndex.save -> DeviceIndex.load (native shard file, chunked upload) searches identically (f32 and f16)."""
+    import torch
+    from sparse_rx import synth
+    c = synth.zipf_corpus_np(30_000, 2_000, 30, seed=11)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(40, c.vocab, 6, seed=12, dist="zipf")
+    for mode, vd in (("bm25", "f32"), ("dot", "f16")):
+        a = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, doc_lengths=c.doc_lengths, avgdl=avgdl, mode=mode,
+                                    val_dtype=vd, tile_log2=11, doc_base=777)
+        exp = a.search(*q, 50)
+        p = str(tmp_path / f"s_{mode}.srx")
+        a.save(p)
+        a.close()
+        b = rx.DeviceIndex.load(p, chunk_bytes=100_000)  # several chunks per array
+        assert (b.n_docs, b.vocab, b.doc_base, b.tile_log2, b.nnz) == (c.n_docs, c.vocab, 777, 11, len(c.indices))
+        got = b.search(*q, 50)
+        b.close()
+        for x, y in zip(got, exp):
+            assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+
+
+def test_corpus_wide_bounds_keep_sharded_search_exact(rx):
+    """Shards searched with corpus-wide score bounds (combine_term_bounds of the shards' fine tables) may return fewer
+    than k rows each, but the merged result equals the single-index result bit for bit; and the bounds do cut the
+    per-shard candidate lists."""
+    import torch
+    from sparse_rx import synth
+    from sparse_rx.index import combine_term_bounds, merge_topk_packed_out_device
+    c = synth.uniform_corpus_np(120_000, 3_000, 40, seed=21)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(64, c.vocab, 8, seed=22)
+    k = 100
+    whole = _dev_index(rx, c, idf, avgdl, tile_log2=12)
+    exp = whole.search(*q, k)
+    whole.close()
+    for shards in (2, 8):
+        bounds = [(c.n_docs * r) // shards for r in range(shards + 1)]
+        ixs = []
+        for r in range(shards):
+            a, b = bounds[r], bounds[r + 1]
+            lo, hi = c.indptr[a], c.indptr[b]
+            ixs.append(rx.DeviceIndex.from_csr(c.indptr[a: b + 1] - lo, c.indices[lo:hi], c.data[lo:hi], idf,
+                                               doc_lengths=c.doc_lengths[a:b], avgdl=avgdl, tile_log2=10, doc_base=a))
+        table = combine_term_bounds([ix.fine_bound for ix in ixs], shards)
+        qd = [torch.as_tensor(x, device="cuda:0") for x in q]
+        rows_local = torch.stack([ix.search_packed_device(*qd, k).clone() for ix in ixs])
+        for ix in ixs:
+            ix.set_term_bound(table)
+        rows_global = torch.stack([ix.search_packed_device(*qd, k).clone() for ix in ixs])
+        torch.cuda.synchronize()
+        for rows, tag in ((rows_local, "local bounds"), (rows_global, "corpus-wide bounds")):
+            out = merge_topk_packed_out_device(rows.contiguous(), k)
+            torch.cuda.synchronize()
+            _assert_exact((out[:, :k].cpu().numpy(), out[:, k:2 * k].contiguous().view(torch.float32).cpu().numpy(),
+                           out[:, 2 * k].cpu().numpy()), exp, f"{tag}, shards={shards}")
+        n_local, n_global = int(rows_local[:, :, 2 * k].sum()), int(rows_global[:, :, 2 * k].sum())
+        assert n_global <= n_local
+        if shards == 8:
+            assert n_global < n_local  # shards return only what can still reach the corpus-wide top k
+        for ix in ixs:
+            ix.close()
