@@ -156,3 +156,39 @@ def test_combined_term_bounds_are_lower_bounds():
             assert comb[t, j] >= own
             better += comb[t, j] > own
     assert better >= 2 * (V - 5)  # the shared bound is the stronger one for K = 10, 100, 1000 on similar shards
+
+
+def _bounds_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sparse_rx
+    from sparse_rx.index import DeviceIndex, combine_term_bounds
+
+    class FakeIndex:  # the collective wiring only needs these two members
+        def __init__(self, t):
+            self.fine_bound, self.table = t, None
+
+        def set_term_bound(self, table):
+            self.table = table
+
+    tabs = [torch.from_numpy(np.random.default_rng(100 + r).random((50, len(DeviceIndex.FINE_KS))).astype(np.float32)) for r in range(world)]
+    ix = FakeIndex(tabs[rank])
+    sparse_rx.global_term_bounds(ix)
+    ret[rank] = bool(ix.table is not None and torch.equal(ix.table, combine_term_bounds(tabs, world)))
+    dist.destroy_process_group()
+
+
+def test_global_term_bounds_collective():
+    world = 3
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_bounds_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=120)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert dict(ret) == {r: True for r in range(world)}
