@@ -41,6 +41,9 @@ WORKLOADS = {
     # secondary workloads (BASELINE.json configs[3], configs[4]); single-GPU numbers are reported in DESIGN.md only
     "c4": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20254,
                kind="splade"),
+    # dev variant of c4 without hot terms (uniform term ids): every tile holds ~4 k postings of ~50 terms
+    "c4u": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20256,
+                kind="splade", zipf_s=0.0),
     "c5": dict(n_docs=10_000_000, vocab=100_000, nnz_per_doc=100, n_queries=256, terms=8, k=100, seed=20255, kind="zipf"),
 }
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
@@ -116,7 +119,8 @@ def main():
     for ci, c in enumerate(my_chunks):
         kind = w.get("kind", "uniform")
         gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]
-        r, cc, tf, dl = gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev)
+        r, cc, tf, dl = (gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev, s=w["zipf_s"]) if "zipf_s" in w
+                         else gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev))
         rows_l.append(r + ci * chunk_docs)
         cols_l.append(cc)
         tf_l.append(tf)
@@ -174,7 +178,7 @@ def main():
     elif kind == "zipf":
         q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=1.0)
     else:
-        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=0.7, weights="learned")
+        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=w.get("zipf_s", 0.7), weights="learned")
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))

@@ -585,6 +585,184 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
     __syncthreads();
 }
 
+// One tile (<= 2^14 docs) holding P <= FLAT_CAP postings of MANY terms (learned-sparse queries: 50 terms with ~80
+// postings each), all terms at once instead of term by term with a barrier and a memory round trip per term:
+//   1. every posting sets its doc's bit in an LDS bitmap; a bit found set marks the doc in a second bitmap (multi-term);
+//   2. second pass (postings come from L1/L2 now): a posting of a single-term doc is the doc's whole score (0 + c) and
+//      becomes a candidate directly; postings of multi-term docs (a few %) go to an LDS list;
+//   3. the list is grouped by doc (hash claim + count + scan + scatter) and each doc's contributions are added in
+//      ascending term order by one thread -- the reference's accumulation order, exactly;
+//   4. singles and multis are folded into the block's running top-k.
+// Returns false (nothing folded, LDS scratch only) when more than FLAT_MCAP postings belong to multi-term docs: the
+// caller then uses the dense accumulators.
+constexpr int FLAT_CAP = 8192;                 // postings per flat tile (32 per thread)
+constexpr int FLAT_NPT = FLAT_CAP / THREADS;
+constexpr int FLAT_MCAP = 2048;                // multi-term postings per flat tile
+constexpr int FLAT_SLOTS = 2048;               // doc hash slots of the grouping step (>= 2 x docs: a multi doc has >= 2 postings)
+constexpr int FLAT_MPT = FLAT_MCAP / THREADS;  // 8
+constexpr int FLAT_MIN_TERMS = 12;             // below this the term-by-term paths are at least as good
+
+template <typename VT>
+__device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_len, int tile_base, int k) {
+    const int tid = threadIdx.x;
+    unsigned *bm1 = S.tbl, *bm2 = S.tbl + 512;
+    int *pre = reinterpret_cast<int *>(S.tbl + 1024);  // [nt + 1] exclusive prefix of m_len: flat posting index -> term
+    unsigned *mcount = S.tbl + 1024 + MAXT + 1;        // multi-term postings collected
+    int *mk_key = reinterpret_cast<int *>(S.tbl + 2048);
+    float *mk_c = reinterpret_cast<float *>(S.tbl + 4096);
+    int *so_key = reinterpret_cast<int *>(S.tbl + 6144);
+    float *so_c = reinterpret_cast<float *>(S.tbl + 8192);
+    int *hk = reinterpret_cast<int *>(S.tbl + 10240);
+    int *hcnt = reinterpret_cast<int *>(S.tbl + 12288);
+    int *hoff = reinterpret_cast<int *>(S.tbl + 14336);
+    const int32_t *post_doc = ix.post_doc;
+    const VT *post_val = reinterpret_cast<const VT *>(ix.post_val);
+
+    unsigned P;
+    const unsigned first = block_excl_scan(tid < nt ? (unsigned)my_len : 0u, S.tk.red, &P);
+    if (tid < nt) pre[tid] = (int)first;
+    if (tid == 0) {
+        pre[nt] = (int)P;
+        *mcount = 0;
+    }
+    reinterpret_cast<uint4 *>(S.tbl)[tid] = make_uint4(0u, 0u, 0u, 0u);  // both bitmaps: 1024 words
+    for (int i = tid; i < FLAT_SLOTS; i += THREADS) {
+        hk[i] = EMPTY_KEY;
+        hcnt[i] = 0;
+    }
+    __syncthreads();
+    // ---- 1. mark ----
+    {
+        int i = 0;
+        for (int f = tid; f < (int)P; f += THREADS) {
+            while (f >= pre[i + 1]) ++i;
+            const int d = post_doc[S.m_start[i] + (f - pre[i])] - tile_base;
+            const unsigned bit = 1u << (d & 31);
+            if (atomicOr(&bm1[d >> 5], bit) & bit) atomicOr(&bm2[d >> 5], bit);
+        }
+    }
+    __syncthreads();
+    // ---- 2. classify: singles to registers, multi postings to the list ----
+    unsigned ubits[FLAT_NPT];
+    int udoc[FLAT_NPT];
+    const unsigned tau = S.tk.tau;
+    {
+        int i = 0;
+#pragma unroll
+        for (int n = 0; n < FLAT_NPT; ++n) {
+            const int f = n * THREADS + tid;
+            ubits[n] = 0u;
+            udoc[n] = 0;
+            if (f < (int)P) {
+                while (f >= pre[i + 1]) ++i;
+                const int64_t g = S.m_start[i] + (f - pre[i]);
+                const int d = post_doc[g] - tile_base;
+                const float c = (load_val(post_val, g) * S.m_idf[i]) * S.m_qw[i];
+                if ((bm2[d >> 5] >> (d & 31)) & 1u) {
+                    const unsigned e = atomicAdd(mcount, 1u);
+                    if (e < (unsigned)FLAT_MCAP) {
+                        mk_key[e] = (d << 8) | i;
+                        mk_c[e] = c;
+                    }
+                } else {
+                    const float sc = 0.0f + c;
+                    const unsigned b = __float_as_uint(sc);
+                    if (sc > 0.0f && b >= tau) {
+                        ubits[n] = b;
+                        udoc[n] = tile_base + d;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned M = *mcount;
+    if (M > (unsigned)FLAT_MCAP) return false;  // uniform
+    // ---- 3. group the multi postings by doc ----
+    int slot[FLAT_MPT];
+#pragma unroll
+    for (int j = 0; j < FLAT_MPT; ++j) {
+        const unsigned e = j * THREADS + tid;
+        slot[j] = -1;
+        if (e < M) {
+            const int d = mk_key[e] >> 8;
+            unsigned h = ((unsigned)d * 0x9E3779B1u) >> (32 - 11);
+            for (;;) {
+                const int old = atomicCAS(&hk[h], EMPTY_KEY, d);
+                if (old == EMPTY_KEY || old == d) break;
+                h = (h + 1) & (FLAT_SLOTS - 1);
+            }
+            slot[j] = (int)h;
+            atomicAdd(&hcnt[h], 1);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int SPT = FLAT_SLOTS / THREADS;  // 8 consecutive slots per thread
+        int c8[SPT];
+        unsigned mine = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            c8[j] = hcnt[tid * SPT + j];
+            mine += (unsigned)c8[j];
+        }
+        unsigned tot;
+        unsigned run = block_excl_scan(mine, S.tk.red, &tot);
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            hoff[tid * SPT + j] = (int)run;
+            run += (unsigned)c8[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FLAT_MPT; ++j) {
+        if (slot[j] >= 0) {
+            const unsigned e = j * THREADS + tid;
+            const int pos = hoff[slot[j]] + atomicSub(&hcnt[slot[j]], 1) - 1;
+            so_key[pos] = mk_key[e];
+            so_c[pos] = mk_c[e];
+        }
+    }
+    __syncthreads();
+    // one thread per doc slot: contributions in ascending term order
+    unsigned mbits[FLAT_MPT];
+    int mdoc[FLAT_MPT];
+#pragma unroll
+    for (int j = 0; j < FLAT_MPT; ++j) {
+        const int sl = tid * FLAT_MPT + j;
+        const int a = hoff[sl];
+        const int b = (sl + 1 < FLAT_SLOTS) ? hoff[sl + 1] : (int)M;
+        mbits[j] = 0u;
+        mdoc[j] = 0;
+        if (b > a) {
+            float sum = 0.0f;
+            int last = -1;
+            for (int n = a; n < b; ++n) {  // selection by term: b - a is 2 or 3 almost always
+                int best = 0x7FFFFFFF, bi = a;
+                for (int m = a; m < b; ++m) {
+                    const int t = so_key[m] & 0xFF;
+                    if (t > last && t < best) {
+                        best = t;
+                        bi = m;
+                    }
+                }
+                sum = sum + so_c[bi];
+                last = best;
+            }
+            const unsigned bb = __float_as_uint(sum);
+            if (sum > 0.0f && bb >= tau) {
+                mbits[j] = bb;
+                mdoc[j] = tile_base + (so_key[a] >> 8);
+            }
+        }
+    }
+    __syncthreads();  // the scratch is free from here: it doubles as the radix histogram of the folds
+    topk_fold<FLAT_NPT, true>(ubits, udoc, k, S.tk, S.tbl);
+    topk_fold<FLAT_MPT, true>(mbits, mdoc, k, S.tk, S.tbl);
+    return true;
+}
+
 __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
@@ -685,7 +863,21 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             }
             const int my_len = hi - lo;
             const unsigned P = block_sum((unsigned)my_len, S.tk.red);
-            if (P > 0 && P <= (unsigned)HASH_CAP) {
+            // many-term queries on a one-tile unit: all terms at once (flat_tile) instead of term by term
+            const bool flat_ok = tps == 1 && nt >= FLAT_MIN_TERMS && P > 0 && P <= (unsigned)FLAT_CAP && !(dbg & 128);
+            bool served = false;
+            if (flat_ok) {
+                if (tid < nt) {
+                    S.m_start[tid] = base + lo;
+                    S.m_len[tid] = my_len;
+                }
+                __syncthreads();
+                served = flat_tile<VT>(S, ix, nt, my_len, su << ix.tile_log2, k);
+                for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
+                __syncthreads();
+            }
+            if (served) {
+            } else if (P > 0 && P <= (unsigned)HASH_CAP) {
                 if (tid < nt) {
                     S.m_start[tid] = base + lo;
                     S.m_len[tid] = my_len;
