@@ -1033,7 +1033,7 @@ __device__ __forceinline__ unsigned wave_radix_kth(KeyFn keyfn, unsigned count, 
         *n_eq = n_cand;
         return mx;
     }
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;  // also used by multi-wave blocks (srx_merge_wave_kernel)
     const int hb = 31 - __clz(mx ^ mn);
     unsigned prefix = mx & ~((2u << hb) - 1u);
     int shift = hb + 1;
@@ -1090,8 +1090,9 @@ __device__ __forceinline__ unsigned wave_radix_kth(KeyFn keyfn, unsigned count, 
 
 // Shrink the wave's list (count > k entries in LDS) to its exact top k; returns tau = key of the k-th.
 // Ties at the k-th score keep the smallest doc ids (the order contract).  Works in place on the LDS list.
-__device__ __noinline__ unsigned wave_list_select(WaveShared &S, unsigned count, int k) {
-    const int lane = threadIdx.x;
+template <typename SH>
+__device__ __noinline__ unsigned wave_list_select(SH &S, unsigned count, int k) {
+    const int lane = threadIdx.x & 63;  // also used by multi-wave blocks (srx_merge_wave_kernel)
     unsigned mx = 0, mn = 0xFFFFFFFFu;
     for (unsigned i = lane; i < count; i += 64) {
         const unsigned x = S.lbits[i];
@@ -1163,6 +1164,44 @@ __device__ __forceinline__ void wave_append(WaveShared &S, WaveTopk &tk, int k, 
             S.ldoc[p] = doc;
         }
         tk.count += (unsigned)__popcll(m2);
+    }
+}
+
+// Rank a wave's final list (count <= k <= 128 entries in S.lbits / S.ldoc) and write the padded result row:
+// wave-level bitonic sort of 128 keys (score bits : ~doc, descending) in the LDS scratch K, two keys per lane,
+// no barrier.
+template <typename SH>
+__device__ __forceinline__ void wave_rank_emit(SH &S, unsigned long long *K, unsigned count, int k, int64_t doc_base,
+                                               int32_t *__restrict__ row_doc, float *__restrict__ row_score) {
+    const int lane = threadIdx.x & 63;
+    wsync();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned i = lane + 64 * j;
+        K[i] = i < count ? (((unsigned long long)S.lbits[i] << 32) | (0x7FFFFFFFu - (unsigned)S.ldoc[i])) : 0ull;
+    }
+    wsync();
+    for (unsigned size = 2; size <= 128; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned pos = 2 * lane - (lane & (stride - 1));
+            const unsigned long long a = K[pos], b = K[pos + stride];
+            const bool desc = (pos & size) == 0;
+            if (desc ? (a < b) : (a > b)) {
+                K[pos] = b;
+                K[pos + stride] = a;
+            }
+            wsync();
+        }
+    }
+    for (unsigned i = lane; i < (unsigned)k; i += 64) {
+        if (i < count) {
+            const unsigned long long x = K[i];
+            row_doc[i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
+            row_score[i] = __uint_as_float((unsigned)(x >> 32));
+        } else {
+            row_doc[i] = -1;
+            row_score[i] = 0.0f;
+        }
     }
 }
 
@@ -1465,39 +1504,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
 #endif
     if (n_splits == 1 && !flagged && out_doc != nullptr) {
         // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
-        // the final row, so the merge kernel can skip the query.  Wave-level bitonic sort of 128 keys
-        // (score bits : ~doc, descending) in LDS (the bitmap is no longer needed), two keys per lane, no barrier.
-        unsigned long long *K = reinterpret_cast<unsigned long long *>(bm);
-        wsync();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned i = lane + 64 * j;
-            K[i] = i < count ? (((unsigned long long)S.lbits[i] << 32) | (0x7FFFFFFFu - (unsigned)S.ldoc[i])) : 0ull;
-        }
-        wsync();
-        for (unsigned size = 2; size <= 128; size <<= 1) {
-            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-                const unsigned pos = 2 * lane - (lane & (stride - 1));
-                const unsigned long long a = K[pos], b = K[pos + stride];
-                const bool desc = (pos & size) == 0;
-                if (desc ? (a < b) : (a > b)) {
-                    K[pos] = b;
-                    K[pos + stride] = a;
-                }
-                wsync();
-            }
-        }
-        const int64_t oo = (int64_t)q * out_row_stride;
-        for (unsigned i = lane; i < (unsigned)k; i += 64) {
-            if (i < count) {
-                const unsigned long long x = K[i];
-                out_doc[oo + i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
-                out_score[oo + i] = __uint_as_float((unsigned)(x >> 32));
-            } else {
-                out_doc[oo + i] = -1;
-                out_score[oo + i] = 0.0f;
-            }
-        }
+        // the final row, so the merge kernel can skip the query.
+        wave_rank_emit(S, reinterpret_cast<unsigned long long *>(bm), count, k, doc_base, out_doc + (int64_t)q * out_row_stride,
+                       out_score + (int64_t)q * out_row_stride);
         if (lane == 0) {
             out_count[(int64_t)q * out_cnt_stride] = (int)count;
             cand_count[list] = -1;  // tells the merge kernel this query is final
@@ -1526,6 +1535,80 @@ struct MergeShared {
     unsigned long long sortkey[KMAX];
     int lstart[64];
 };
+
+// Wave-level final merge for the common small case (n_lists * k <= 1024 candidates per query, k <= 128: the splits /
+// tiers of one shard, or 8 shards' top-100): one wavefront per query, no barrier.  The candidates are compacted into
+// an LDS list, the exact list selection of tier 1 shrinks it to k and the wave ranks and writes the row.
+constexpr int MW_CAP = 1024;
+struct MergeWaveShared {
+    unsigned lbits[MW_CAP];
+    int ldoc[MW_CAP];
+    unsigned hist[256];
+    unsigned long long sortkey[128];
+};
+
+__global__ __launch_bounds__(THREADS) void srx_merge_wave_kernel(const int32_t *__restrict__ in_doc,
+                                                                 const float *__restrict__ in_score,
+                                                                 const int32_t *__restrict__ in_count, int nq, int n_lists,
+                                                                 int k, int gathered, int64_t row_stride,
+                                                                 int64_t cnt_stride, int64_t doc_base,
+                                                                 int32_t *__restrict__ out_doc,
+                                                                 float *__restrict__ out_score,
+                                                                 int32_t *__restrict__ out_count, int64_t out_row_stride,
+                                                                 int64_t out_cnt_stride) {
+    __shared__ MergeWaveShared MW[WAVES];
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
+    MergeWaveShared &S = MW[threadIdx.x >> 6];
+    // list lengths first (one round trip), then every candidate slot of the query in one batch of loads (a second
+    // round trip), then a ballot compaction of the positive scores into the LDS list
+    for (int l = lane; l < n_lists; l += 64) {
+        // layout 0: [nq][n_lists][k] (+ counts [nq][n_lists]); gathered: [n_lists][nq][k] (+ [n_lists][nq])
+        const int64_t li = gathered ? ((int64_t)l * nq + q) : ((int64_t)q * n_lists + l);
+        S.hist[l] = (unsigned)max(0, min(in_count[li * cnt_stride], k));  // n_lists <= 256 (host check); hist is free until the selection
+    }
+    wsync();
+    constexpr int MW_NPL = MW_CAP / 64;  // candidate slots per lane
+    float sc[MW_NPL];
+    int dd[MW_NPL];
+    const int span = n_lists * k;
+#pragma unroll
+    for (int j = 0; j < MW_NPL; ++j) {
+        const int c = j * 64 + lane;
+        sc[j] = 0.0f;
+        dd[j] = 0;
+        if (c < span) {
+            const int l = c / k, r = c - l * k;
+            if (r < (int)S.hist[l]) {
+                const int64_t li = gathered ? ((int64_t)l * nq + q) : ((int64_t)q * n_lists + l);
+                const int64_t a = li * row_stride + r;  // row_stride = k for plain lists, 2k+1 for packed rows
+                sc[j] = in_score[a];
+                dd[j] = in_doc[a];
+            }
+        }
+    }
+    unsigned count = 0;  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < MW_NPL; ++j) {
+        const bool ok = sc[j] > 0.0f;
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const unsigned p = count + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            S.lbits[p] = __float_as_uint(sc[j]);
+            S.ldoc[p] = dd[j];
+        }
+        count += (unsigned)__popcll(m);
+    }
+    wsync();
+    if (count > (unsigned)k) {
+        wave_list_select(S, count, k);
+        count = (unsigned)k;
+    }
+    wave_rank_emit(S, S.sortkey, count, k, doc_base, out_doc + (int64_t)q * out_row_stride, out_score + (int64_t)q * out_row_stride);
+    if (lane == 0) out_count[(int64_t)q * out_cnt_stride] = (int)count;
+}
 
 __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__restrict__ in_doc,
                                                             const float *__restrict__ in_score,
@@ -1861,8 +1944,14 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
                            work, cand_doc, cand_score, cand_count);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
-                       p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score, out_count, ors, ocs);
+    if (k <= W_KMAX && (int64_t)p.lists_per_q * k <= MW_CAP && p.lists_per_q <= 256 && !(dbg & 256))
+        hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cand_doc,
+                           cand_score, cand_count, nq, p.lists_per_q, k, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc,
+                           out_score, out_count, ors, ocs);
+    else
+        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
+                           p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score,
+                           out_count, ors, ocs);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(ev[3], stream));
@@ -1961,8 +2050,13 @@ int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, con
         lists = groups;
         ++level;
     }
-    hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
-                       lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs);
+    if (k <= W_KMAX && (int64_t)lists * k <= MW_CAP && lists <= 256)
+        hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cur_doc,
+                           cur_score, cur_count, nq, lists, k, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score,
+                           out_count, ors, ocs);
+    else
+        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
+                           lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs);
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
