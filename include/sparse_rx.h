@@ -169,6 +169,19 @@ int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *
                         int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
+/* Dense INT8 side of the same service.  Replaces quantized_dot_product_batch
+ * (rag_system/core/retriever_registry.py:90-117; NumPy twin :538-548) + the top-k that follows it (:505-519):
+ *   score[q][d] = f32( f64(sum_i queries[q][i] * corpus[d][i]) * query_scale[q] * corpus_scale[d] )   (int8 x int8 -> int32,
+ *   scaled in fp64 like the reference's NumPy scalars), results = the k largest scores > 0 per query, ranked
+ *   (score desc, doc asc), ids = doc_base + row, rows padded with -1 / 0, counts in out_count.
+ * corpus i8[n_docs][dim], queries i8[nq][dim] row-major, 16-byte aligned, dim in {32,64,96,128,192,256,384,512,768,1024}
+ * (pad rows with zeros otherwise); all pointers are device pointers; asynchronous on `stream`. */
+int64_t srx_dense_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k);
+int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                        const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                        int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace, int64_t workspace_bytes,
+                        void *stream);
+
 /* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = tier-1
  * wave kernel, h_ms[1] = tier-2 block kernel, h_ms[2] = merge kernel, h_ms[3] = whole call (milliseconds,
  * hipEventElapsedTime between events recorded on the search stream around each kernel).  Synchronises the

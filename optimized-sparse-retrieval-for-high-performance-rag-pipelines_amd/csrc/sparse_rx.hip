@@ -2115,6 +2115,183 @@ SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const i
     return SRX_OK;
 }
 
+// ================================================================================================
+// Dense INT8 side of the same service: quantized_dot_product_batch
+// (rag_system/core/retriever_registry.py:90-117; NumPy twin :538-548) + the same top-k (:505-519).
+//   score[q][d] = f32( f64(sum_i query_i8[q][i] * corpus_i8[d][i]) * query_scale[q] * corpus_scale[d] )
+// The integer dot products are one MFMA GEMM (v_mfma_i32_32x32x32_i8, exact); the two scalings are done in fp64 like
+// the reference's NumPy scalars (int32 * float32 -> float64), so the stored fp32 score is the reference's bit for bit.
+// First form: the scaled scores go through HBM once (a [query batch][n_docs] fp32 matrix in the workspace) and the
+// block top-k machinery of the sparse path ranks each row; only scores > 0 are results (retriever_registry.py:519).
+// ================================================================================================
+namespace {
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// One wave = 32 docs x (all queries, 32 at a time); a workgroup = 4 waves = 128 consecutive docs.  The wave keeps its
+// docs' B fragments in registers for the whole query loop (KS k-steps of 32: lane l holds corpus[d0 + (l & 31)]
+// [32 s + 16 (l >> 5) .. + 15], one 16-byte load); the queries' A fragments (the same map on the query rows) stream
+// from L2.  D[row = query][col = doc]: lane l holds doc l & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+template <int KS>
+__global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8_t *__restrict__ corpus,
+                                                                       const float *__restrict__ corpus_scale,
+                                                                       int64_t n_docs, const int8_t *__restrict__ queries,
+                                                                       const float *__restrict__ query_scale, int nq,
+                                                                       float *__restrict__ scores, int64_t ld) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
+    if (d0 >= n_docs) return;
+    constexpr int DIM = KS * 32;
+    const int64_t d = d0 + r;
+    const bool dok = d < n_docs;
+    v4i B[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        B[s] = (v4i){0, 0, 0, 0};
+        if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+    }
+    const double ds = dok ? (double)corpus_scale[d] : 0.0;
+    for (int q0 = 0; q0 < nq; q0 += 32) {
+        const int qa = q0 + r;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            v4i A = {0, 0, 0, 0};
+            if (qa < nq) A = *reinterpret_cast<const v4i *>(queries + (int64_t)qa * DIM + s * 32 + 16 * h);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
+        }
+        if (dok) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (q < nq) scores[(int64_t)q * ld + d] = (float)(((double)acc[reg] * (double)query_scale[q]) * ds);
+            }
+        }
+    }
+}
+
+// Row top-k: one workgroup per (query, split of the doc range) folds its slice of the score row into an exact lazy
+// top-k list (topk_fold, the sparse path's machinery); the merge kernels rank the splits' lists.
+constexpr int DENSE_NPT = 16;
+__global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_docs,
+                                                                 int nq, int k, int n_splits, int64_t doc_base,
+                                                                 int32_t *__restrict__ cand_doc,
+                                                                 float *__restrict__ cand_score,
+                                                                 int32_t *__restrict__ cand_count) {
+    __shared__ MergeShared M;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / n_splits, split = blockIdx.x - q * n_splits;
+    if (q >= nq) return;
+    const int64_t lo = n_docs * split / n_splits, hi = n_docs * (split + 1) / n_splits;
+    if (tid == 0) {
+        M.tk.count = 0;
+        M.tk.tau = 0;
+    }
+    __syncthreads();
+    const float *row = scores + (int64_t)q * ld;
+    for (int64_t c0 = lo; c0 < hi; c0 += (int64_t)THREADS * DENSE_NPT) {
+        unsigned ubits[DENSE_NPT];
+        int udoc[DENSE_NPT];
+        const unsigned tau = M.tk.tau;
+#pragma unroll
+        for (int n = 0; n < DENSE_NPT; ++n) {
+            const int64_t c = c0 + (int64_t)n * THREADS + tid;
+            float x = 0.0f;
+            if (c < hi) x = row[c];
+            const unsigned b = __float_as_uint(x);
+            ubits[n] = (x > 0.0f && b >= tau) ? b : 0u;
+            udoc[n] = (int)(doc_base + c);
+        }
+        topk_fold<DENSE_NPT, true>(ubits, udoc, k, M.tk, M.hist);
+    }
+    __syncthreads();
+    topk_shrink(k, M.tk, M.hist);
+    const unsigned cnt = M.tk.count;
+    const int64_t o = (int64_t)blockIdx.x * k;
+    for (unsigned i = tid; i < cnt; i += THREADS) {
+        cand_doc[o + i] = M.tk.doc[i];
+        cand_score[o + i] = __uint_as_float(M.tk.bits[i]);
+    }
+    if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
+}
+
+constexpr int DENSE_QB = 256;  // queries per pass: bounds the score matrix in the workspace (256 x n_docs x 4 B)
+int dense_splits(int64_t n_docs, int nq, int k) {
+    int64_t s = 2048 / (nq > 0 ? nq : 1);  // >= 2048 workgroups when the batch is small
+    const int64_t by_docs = n_docs / (THREADS * DENSE_NPT * 4);
+    if (s > by_docs) s = by_docs;
+    const int64_t cap = (MERGE_NPT * THREADS) / (k > 0 ? k : 1);  // one merge level
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+}  // namespace
+
+SRX_API int64_t srx_dense_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_workspace_bytes: bad argument%s");
+    const int qb = nq < DENSE_QB ? nq : DENSE_QB;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, qb, k);
+    return (int64_t)qb * ld * 4 + (int64_t)qb * ns * k * 8 + (int64_t)qb * ns * 4 + 1024;
+}
+
+SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                                const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                                int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                                int64_t workspace_bytes, void *stream_v) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: need n_docs > 0, 1 <= k <= 1024%s");
+    if (dim <= 0 || dim % 32 != 0 || dim > 1024)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be a multiple of 32, <= 1024 (pad the rows with zeros)%s");
+    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: doc_base + n_docs must fit int32%s");
+    if (nq == 0) return SRX_OK;
+    if (!corpus || !corpus_scale || !queries || !query_scale || !out_doc || !out_score || !out_count)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_i8: null pointer%s");
+    if (((uintptr_t)corpus | (uintptr_t)queries) & 15) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: corpus / queries must be 16-byte aligned%s");
+    const int64_t need = srx_dense_workspace_bytes(nq, n_docs, k);
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_i8: workspace too small%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int qbmax = nq < DENSE_QB ? nq : DENSE_QB;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, qbmax, k);
+    float *scores = (float *)workspace;
+    int32_t *cand_doc = (int32_t *)(scores + (int64_t)qbmax * ld);
+    float *cand_score = (float *)(cand_doc + (int64_t)qbmax * ns * k);
+    int32_t *cand_count = (int32_t *)(cand_score + (int64_t)qbmax * ns * k);
+    const unsigned gblocks = (unsigned)((n_docs + 32 * WAVES - 1) / (32 * WAVES));
+    for (int q0 = 0; q0 < nq; q0 += DENSE_QB) {
+        const int qb = nq - q0 < DENSE_QB ? nq - q0 : DENSE_QB;
+        const int8_t *qp = queries + (int64_t)q0 * dim;
+        const float *qs = query_scale + q0;
+#define SRX_DENSE_LAUNCH(KSV)                                                                                             \
+    hipLaunchKernelGGL(srx_dense_i8_scores_kernel<KSV>, dim3(gblocks), dim3(THREADS), 0, stream, corpus, corpus_scale, n_docs, \
+                       qp, qs, qb, scores, ld)
+        switch (dim / 32) {
+            case 1: SRX_DENSE_LAUNCH(1); break;
+            case 2: SRX_DENSE_LAUNCH(2); break;
+            case 3: SRX_DENSE_LAUNCH(3); break;
+            case 4: SRX_DENSE_LAUNCH(4); break;
+            case 6: SRX_DENSE_LAUNCH(6); break;
+            case 8: SRX_DENSE_LAUNCH(8); break;
+            case 12: SRX_DENSE_LAUNCH(12); break;
+            case 16: SRX_DENSE_LAUNCH(16); break;
+            case 24: SRX_DENSE_LAUNCH(24); break;
+            case 32: SRX_DENSE_LAUNCH(32); break;
+            default: return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be 32, 64, 96, 128, 192, 256, 384, 512, 768 or 1024 (pad the rows with zeros)%s");
+        }
+#undef SRX_DENSE_LAUNCH
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb,
+                           k, ns, doc_base, cand_doc, cand_score, cand_count);
+        HIP_TRY(hipGetLastError());
+        const int rc = merge_impl(device, cand_doc, cand_score, cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1,
+                                  out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_count + q0, (int64_t)k, (int64_t)1,
+                                  nullptr, 0, stream_v);
+        if (rc != SRX_OK) return rc;
+    }
+    return SRX_OK;
+}
+
 #ifdef SRX_STAMP
 // Diagnostic build only: cumulative s_memtime ticks per kernel segment (see STAMP in srx_wave_kernel); resets.
 extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {

@@ -68,3 +68,33 @@ def topk_ranked(scores: np.ndarray, k: int):
     order = np.lexsort((np.arange(len(s)), -s.astype(np.float64)))
     order = order[: min(k, len(s))]
     return order.astype(np.int64), s[order]
+
+
+def int8_similarities(queries_int8, corpus_int8, query_scales, corpus_scales):
+    """retriever_registry.py:538-548 (the NumPy twin of quantized_dot_product_batch :90-117, symmetric scheme):
+    similarities[q, d] = f32( int32 dot * query_scale (f32) * doc_scale (f32) ) with NumPy scalar promotion
+    (int32 * float32 -> float64, * float32 -> float64, stored into a float32 array)."""
+    q = np.asarray(queries_int8).astype(np.int32)
+    c = np.asarray(corpus_int8).astype(np.int32)
+    dots = q @ c.T  # exact: |dot| <= dim * 127 * 127 < 2^31
+    qs = np.asarray(query_scales, dtype=np.float32).astype(np.float64)[:, None]
+    cs = np.asarray(corpus_scales, dtype=np.float32).astype(np.float64)[None, :]
+    return ((dots.astype(np.float64) * qs) * cs).astype(np.float32)
+
+
+def dense_topk(similarities, k):
+    """Ranked top-k of every row with the engine's contract: score > 0 only (retriever_registry.py:515-519),
+    (score desc, doc asc), padded with -1 / 0."""
+    sims = np.asarray(similarities, dtype=np.float32)
+    nq = sims.shape[0]
+    out_d = np.full((nq, k), -1, np.int32)
+    out_s = np.zeros((nq, k), np.float32)
+    out_n = np.zeros(nq, np.int32)
+    for i in range(nq):
+        d, s = topk_ranked(sims[i], k)
+        keep = s > 0
+        d, s = d[keep], s[keep]
+        out_d[i, : len(d)] = d
+        out_s[i, : len(d)] = s
+        out_n[i] = len(d)
+    return out_d, out_s, out_n

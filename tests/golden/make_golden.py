@@ -16,6 +16,9 @@ reference produced for them:
                        through ``simd_tfidf_score`` (pipeline twin) with its idf variant
   registry_small.json  ``OptimizedBM25Retriever`` (registry twin) results on the same text corpus,
                        bm25 and the registry's tfidf setting (k1=1000, b=0)
+  dense_int8.npz/.json ``QuantizedEmbeddingRetriever`` (symmetric INT8): quantized corpus, per-query similarity rows
+                       and ``search`` results for recorded embeddings (run with the argument ``dense`` to refresh
+                       only these)
 
 numba is not installed here, so the reference runs its own NumPy / plain-Python fallbacks
 (NUMBA_AVAILABLE=False, retrieval.py:22-33).
@@ -244,10 +247,52 @@ def make_registry_fixture(tmp, corpus, queries):
         json.dump(out, f, ensure_ascii=False, indent=0)
 
 
+def make_dense_fixture():
+    """dense_int8.npz: embeddings pushed through the reference's QuantizedEmbeddingRetriever (symmetric INT8):
+    ``_quantize_embeddings`` -> corpus_int8 / corpus_scales, and the real ``search`` (query quantization, NumPy
+    similarity twin of quantized_dot_product_batch, top-k, score > 0 filter) with the simulated query-embedding
+    generator replaced by the recorded query embeddings."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        import rag_system.core.retriever_registry as ref_reg
+        rng = np.random.default_rng(4242)
+        n_docs, dim, nq = 300, 48, 12
+        emb = rng.standard_normal((n_docs, dim)).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        emb[7] = emb[3]            # exact duplicates: score ties
+        emb[11] = 0.0              # an all-zero row (scale clamps to 1e-8)
+        qemb = rng.standard_normal((nq, dim)).astype(np.float32)
+        qemb /= np.linalg.norm(qemb, axis=1, keepdims=True)
+        qemb[2] = emb[3] * 0.5     # a query parallel to the duplicated docs
+        r = ref_reg.QuantizedEmbeddingRetriever("dpr", "fixture", embedding_dim=dim)
+        r.doc_ids = [f"d{i}" for i in range(n_docs)]
+        r.corpus_embeddings_int8, r.corpus_scales = r._quantize_embeddings(emb)
+        qtexts = {f"q{i}": f"query {i}" for i in range(nq)}
+        lookup = {t: qemb[i] for i, t in enumerate(qtexts.values())}
+        r._generate_query_embedding = lambda text: lookup[text]
+        sims, qi8, qsc = [], [], []
+        for i in range(nq):  # the similarity rows the search ranks (same calls as retriever_registry.py:482-503)
+            s = np.max(np.abs(qemb[i]))
+            q8 = np.round(qemb[i] / s * 127.0).astype(np.int8)
+            qs = np.array([s / 127.0], dtype=np.float32)
+            sims.append(r._numpy_quantized_similarity(q8, qs).copy())
+            qi8.append(q8)
+            qsc.append(qs[0])
+        results = {str(k): r.search(qtexts, top_k=k) for k in (5, 20)}
+    np.savez_compressed(os.path.join(OUT, "dense_int8.npz"), emb=emb, qemb=qemb, corpus_int8=r.corpus_embeddings_int8,
+                        corpus_scales=r.corpus_scales, query_int8=np.stack(qi8), query_scales=np.array(qsc, dtype=np.float32),
+                        similarities=np.stack(sims))
+    with open(os.path.join(OUT, "dense_int8.json"), "w", encoding="utf-8") as f:
+        json.dump({"doc_ids": r.doc_ids, "qids": list(qtexts), "results": results}, f, indent=0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dense":  # only the dense fixture (the others stay as committed)
+        make_dense_fixture()
+        sys.exit(0)
     with tempfile.TemporaryDirectory() as tmp:
         corpus, queries = make_text_fixture(tmp)
         make_csr_fixture(tmp)
         make_registry_fixture(tmp, corpus, queries)
+    make_dense_fixture()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
