@@ -1555,11 +1555,12 @@ __global__ __launch_bounds__(THREADS) void srx_merge_wave_kernel(const int32_t *
                                                                  int32_t *__restrict__ out_doc,
                                                                  float *__restrict__ out_score,
                                                                  int32_t *__restrict__ out_count, int64_t out_row_stride,
-                                                                 int64_t out_cnt_stride) {
+                                                                 int64_t out_cnt_stride, const int *__restrict__ gate) {
     __shared__ MergeWaveShared MW[WAVES];
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (q >= nq) return;
+    if (gate != nullptr && *gate == 0) return;  // optional device-side switch (dense fallback pass)
     if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
     MergeWaveShared &S = MW[threadIdx.x >> 6];
     // list lengths first (one round trip), then every candidate slot of the query in one batch of loads (a second
@@ -1618,12 +1619,13 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
                                                             int64_t doc_base, int32_t *__restrict__ out_doc,
                                                             float *__restrict__ out_score,
                                                             int32_t *__restrict__ out_count, int64_t out_row_stride,
-                                                            int64_t out_cnt_stride) {
+                                                            int64_t out_cnt_stride, const int *__restrict__ gate) {
     __shared__ MergeShared M;
     const int tid = threadIdx.x;
     const int q = blockIdx.x / n_groups;
     const int g = blockIdx.x - q * n_groups;
     if (q >= nq) return;
+    if (gate != nullptr && *gate == 0) return;  // optional device-side switch (dense fallback pass)
     if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
     const int l0 = g * lists_per_group;
     const int l1 = min(l0 + lists_per_group, n_lists);
@@ -1947,11 +1949,11 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     if (k <= W_KMAX && (int64_t)p.lists_per_q * k <= MW_CAP && p.lists_per_q <= 256 && !(dbg & 256))
         hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cand_doc,
                            cand_score, cand_count, nq, p.lists_per_q, k, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc,
-                           out_score, out_count, ors, ocs);
+                           out_score, out_count, ors, ocs, (const int *)nullptr);
     else
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
                            p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score,
-                           out_count, ors, ocs);
+                           out_count, ors, ocs, (const int *)nullptr);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(ev[3], stream));
@@ -2015,7 +2017,7 @@ namespace {
 int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, const int32_t *in_count, int32_t nq,
                int32_t n_lists, int32_t k, int lay, int64_t row_stride, int64_t cnt_stride, int32_t *out_doc,
                float *out_score, int32_t *out_count, int64_t ors, int64_t ocs, void *workspace, int64_t workspace_bytes,
-               void *stream_v) {
+               void *stream_v, const int *gate = nullptr) {
     if (nq < 0 || n_lists <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_merge_topk: bad argument%s");
     if (nq == 0) return SRX_OK;
     if (!in_doc || !in_score || !in_count || !out_doc || !out_score || !out_count)
@@ -2039,7 +2041,7 @@ int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, con
         int32_t *oc = (int32_t *)(os + (int64_t)nq * groups * k);
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cur_doc,
                            cur_score, cur_count, nq, lists, k, fan, groups, 0, lay, row_stride, cnt_stride, (int64_t)0, od, os,
-                           oc, (int64_t)k, (int64_t)1);
+                           oc, (int64_t)k, (int64_t)1, gate);
         HIP_TRY(hipGetLastError());
         lay = 0;
         row_stride = k;
@@ -2053,10 +2055,10 @@ int merge_impl(int32_t device, const int32_t *in_doc, const float *in_score, con
     if (k <= W_KMAX && (int64_t)lists * k <= MW_CAP && lists <= 256)
         hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cur_doc,
                            cur_score, cur_count, nq, lists, k, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score,
-                           out_count, ors, ocs);
+                           out_count, ors, ocs, gate);
     else
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
-                           lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs);
+                           lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs, gate);
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
@@ -2127,6 +2129,8 @@ SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const i
 namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate counters: one 128-byte line each (all waves
+                                      // add to these: counters sharing a line serialise in one L2 channel)
 
 // One wave = 32 docs x (all queries, 32 at a time); a workgroup = 4 waves = 128 consecutive docs.  The wave keeps its
 // docs' B fragments in registers for the whole query loop (KS k-steps of 32: lane l holds corpus[d0 + (l & 31)]
@@ -2137,7 +2141,57 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
                                                                        const float *__restrict__ corpus_scale,
                                                                        int64_t n_docs, const int8_t *__restrict__ queries,
                                                                        const float *__restrict__ query_scale, int nq,
-                                                                       float *__restrict__ scores, int64_t ld) {
+                                                                       float *__restrict__ scores, int64_t ld,
+                                                                       const int *__restrict__ gate) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
+    if (d0 >= n_docs) return;
+    if (gate != nullptr && *gate == 0) return;  // fallback pass: only runs when some query's candidate buffer overflowed
+    constexpr int DIM = KS * 32;
+    const int64_t d = d0 + r;
+    const bool dok = d < n_docs;
+    v4i B[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        B[s] = (v4i){0, 0, 0, 0};
+        if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+    }
+    const double ds = dok ? (double)corpus_scale[d] : 0.0;
+    for (int q0 = 0; q0 < nq; q0 += 32) {
+        const int qa = q0 + r;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            v4i A = {0, 0, 0, 0};
+            if (qa < nq) A = *reinterpret_cast<const v4i *>(queries + (int64_t)qa * DIM + s * 32 + 16 * h);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
+        }
+        // the tile's 32 query scales: one coalesced load, then a lane permute per accumulator row (a global load per
+        // row would put 16 dependent L1 round trips behind every tile)
+        const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const float qsr = __shfl(qs_mine, row);
+            if (dok && q0 + row < nq) scores[(int64_t)(q0 + row) * ld + d] = (float)(((double)acc[reg] * (double)qsr) * ds);
+        }
+    }
+}
+
+// The same GEMM with the top-k filter fused in: instead of writing the score, a lane keeps it only if it can still
+// reach the query's top k (score > 0 and >= tau[q], a valid lower bound of the k-th best score taken from a sample of
+// the corpus) and appends (doc, score) to the query's candidate buffer (one atomicAdd per query row and lane half).
+// A full buffer raises the query's overflow flag (the caller then re-ranks that query through the score matrix).
+template <int KS>
+__global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
+                                                                       const float *__restrict__ corpus_scale,
+                                                                       int64_t n_docs, const int8_t *__restrict__ queries,
+                                                                       const float *__restrict__ query_scale, int nq,
+                                                                       const unsigned *__restrict__ tau, int cap,
+                                                                       int64_t doc_base, int32_t *__restrict__ buf_doc,
+                                                                       float *__restrict__ buf_score,
+                                                                       int *__restrict__ buf_cnt, int *__restrict__ ovf,
+                                                                       int *__restrict__ any_ovf) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
     if (d0 >= n_docs) return;
@@ -2160,11 +2214,52 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
             if (qa < nq) A = *reinterpret_cast<const v4i *>(queries + (int64_t)qa * DIM + s * 32 + 16 * h);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
         }
-        if (dok) {
+        // Survivors of the 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator registers
+        // are in flight together -- one global round trip per tile instead of one per register with survivors:
+        // scores + pass bits; one atomicAdd per (query row, lane half) with survivors; broadcast the bases and store.
+        float scv[16];
+        unsigned passbits = 0;
+        // the tile's 32 query scales and thresholds: one coalesced load each, then a lane permute per accumulator row
+        const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
+        const unsigned tau_mine = qa < nq ? tau[qa] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // differs between the two lane halves
+            const float qsr = __shfl(qs_mine, row);
+            const unsigned taur = (unsigned)__shfl((int)tau_mine, row);
+            scv[reg] = dok ? (float)(((double)acc[reg] * (double)qsr) * ds) : 0.0f;
+            if (q0 + row < nq && scv[reg] > 0.0f && __float_as_uint(scv[reg]) >= taur) passbits |= 1u << reg;
+        }
+        if (__ballot(passbits != 0u) != 0ull) {  // uniform; about 6 survivors per tile at the design point
+            int basev[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (q < nq) scores[(int64_t)q * ld + d] = (float)(((double)acc[reg] * (double)query_scale[q]) * ds);
+                const bool pass = (passbits >> reg) & 1u;
+                const unsigned long long m = __ballot(pass);
+                const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);  // my half's survivors: one query row
+                basev[reg] = 0;
+                if (pass && (mh & ((1u << r) - 1u)) == 0u)  // first survivor of the row reserves room for all of them
+                    basev[reg] = atomicAdd(&buf_cnt[(q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * DENSE_CNT_STRIDE], __popc(mh));
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const bool pass = (passbits >> reg) & 1u;
+                const unsigned long long m = __ballot(pass);
+                if (m != 0ull) {  // uniform
+                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);
+                    const int base = __shfl(basev[reg], h * 32 + (mh ? __ffs((int)mh) - 1 : 0));
+                    if (pass) {
+                        const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const int p = base + __popc(mh & ((1u << r) - 1u));
+                        if (p < cap) {
+                            buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d);
+                            buf_score[(int64_t)q * cap + p] = scv[reg];
+                        } else {
+                            ovf[q] = 1;
+                            *any_ovf = 1;
+                        }
+                    }
+                }
             }
         }
     }
@@ -2173,22 +2268,39 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 // Row top-k: one workgroup per (query, split of the doc range) folds its slice of the score row into an exact lazy
 // top-k list (topk_fold, the sparse path's machinery); the merge kernels rank the splits' lists.
 constexpr int DENSE_NPT = 16;
+// mode 0: rank scores[q][lo..hi) (ids = doc_base + column).  mode 1: rank the query's candidate buffer (buf_doc /
+// scores hold (doc, score) pairs, buf_cnt[q] of them).  only_flag: +1 = only queries with ovf[q] != 0, -1 = only queries
+// with ovf[q] == 0, 0 = all; a skipped query writes count -1 for its first list (the merge kernels then leave its
+// output row alone).  tau_out (optional): the k-th best score's bits when the list holds k entries, else 0.
 __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_docs,
-                                                                 int nq, int k, int n_splits, int64_t doc_base,
+                                                                 int nq, int k, int n_splits, int64_t doc_base, int mode,
+                                                                 const int32_t *__restrict__ buf_doc,
+                                                                 const int *__restrict__ buf_cnt, int cap,
+                                                                 const int *__restrict__ ovf, int only_flag,
+                                                                 const int *__restrict__ gate,
                                                                  int32_t *__restrict__ cand_doc,
                                                                  float *__restrict__ cand_score,
-                                                                 int32_t *__restrict__ cand_count) {
+                                                                 int32_t *__restrict__ cand_count,
+                                                                 unsigned *__restrict__ tau_out) {
     __shared__ MergeShared M;
     const int tid = threadIdx.x;
     const int q = blockIdx.x / n_splits, split = blockIdx.x - q * n_splits;
     if (q >= nq) return;
-    const int64_t lo = n_docs * split / n_splits, hi = n_docs * (split + 1) / n_splits;
+    if (gate != nullptr && *gate == 0) return;
+    if (only_flag != 0 && ((ovf[q] != 0) != (only_flag > 0))) {
+        if (tid == 0) cand_count[blockIdx.x] = split == 0 ? -1 : 0;
+        return;
+    }
+    int64_t total = n_docs;
+    if (mode == 1) total = min(buf_cnt[q * DENSE_CNT_STRIDE], cap);
+    const int64_t lo = total * split / n_splits, hi = total * (split + 1) / n_splits;
     if (tid == 0) {
         M.tk.count = 0;
         M.tk.tau = 0;
     }
     __syncthreads();
     const float *row = scores + (int64_t)q * ld;
+    const int32_t *drow = mode == 1 ? buf_doc + (int64_t)q * ld : nullptr;
     for (int64_t c0 = lo; c0 < hi; c0 += (int64_t)THREADS * DENSE_NPT) {
         unsigned ubits[DENSE_NPT];
         int udoc[DENSE_NPT];
@@ -2197,10 +2309,14 @@ __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__
         for (int n = 0; n < DENSE_NPT; ++n) {
             const int64_t c = c0 + (int64_t)n * THREADS + tid;
             float x = 0.0f;
-            if (c < hi) x = row[c];
+            int dd = 0;
+            if (c < hi) {
+                x = row[c];
+                dd = mode == 1 ? drow[c] : (int)(doc_base + c);
+            }
             const unsigned b = __float_as_uint(x);
             ubits[n] = (x > 0.0f && b >= tau) ? b : 0u;
-            udoc[n] = (int)(doc_base + c);
+            udoc[n] = dd;
         }
         topk_fold<DENSE_NPT, true>(ubits, udoc, k, M.tk, M.hist);
     }
@@ -2208,14 +2324,21 @@ __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__
     topk_shrink(k, M.tk, M.hist);
     const unsigned cnt = M.tk.count;
     const int64_t o = (int64_t)blockIdx.x * k;
+    unsigned mn = 0xFFFFFFFFu;
     for (unsigned i = tid; i < cnt; i += THREADS) {
         cand_doc[o + i] = M.tk.doc[i];
         cand_score[o + i] = __uint_as_float(M.tk.bits[i]);
+        mn = min(mn, M.tk.bits[i]);
     }
     if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
+    if (tau_out != nullptr) {  // n_splits == 1 here
+        const SumMaxMin rr = block_sum_max_min(0u, 0u, mn, M.tk.red);
+        if (tid == 0) tau_out[q] = cnt >= (unsigned)k ? rr.mn : 0u;
+    }
 }
 
-constexpr int DENSE_QB = 256;  // queries per pass: bounds the score matrix in the workspace (256 x n_docs x 4 B)
+constexpr int DENSE_QB = 256;     // queries per pass: bounds the score matrix in the workspace (256 x n_docs x 4 B)
+constexpr int DENSE_CAP = 65536;  // candidate buffer entries per query of the filtered path
 int dense_splits(int64_t n_docs, int nq, int k) {
     int64_t s = 2048 / (nq > 0 ? nq : 1);  // >= 2048 workgroups when the batch is small
     const int64_t by_docs = n_docs / (THREADS * DENSE_NPT * 4);
@@ -2225,14 +2348,55 @@ int dense_splits(int64_t n_docs, int nq, int k) {
     if (s < 1) s = 1;
     return (int)s;
 }
+// Sample size of the threshold pass: the k-th best score of S docs leaves about k * n_docs / S survivors per query;
+// aim at DENSE_CAP / 8.  0 = corpus too small for the filtered path to pay.
+int64_t dense_sample(int64_t n_docs, int k) {
+    int64_t S = (8 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
+    if (S < 16384) S = 16384;
+    S = (S + 127) / 128 * 128;
+    return (S * 4 <= n_docs) ? S : 0;
+}
+struct DenseWs {
+    float *scores;
+    int32_t *cand_doc;
+    float *cand_score;
+    int32_t *cand_count;
+    unsigned *tau;
+    int *buf_cnt, *ovf, *any_ovf;
+    int32_t *buf_doc;
+    float *buf_score;
+    int64_t bytes;
+};
+DenseWs dense_ws(void *base, int nq, int64_t n_docs, int k) {
+    const int qb = nq < DENSE_QB ? nq : DENSE_QB;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, qb, k);
+    const bool filt = dense_sample(n_docs, k) > 0;
+    DenseWs w;
+    char *p = (char *)base;
+    auto take = [&](int64_t bytes) {
+        char *r = p;
+        p += (bytes + 255) / 256 * 256;
+        return r;
+    };
+    w.scores = (float *)take((int64_t)qb * ld * 4);
+    w.cand_doc = (int32_t *)take((int64_t)qb * ns * k * 4);
+    w.cand_score = (float *)take((int64_t)qb * ns * k * 4);
+    w.cand_count = (int32_t *)take((int64_t)qb * ns * 4);
+    w.tau = (unsigned *)take((int64_t)qb * 4);
+    w.buf_cnt = (int *)take((int64_t)(qb * DENSE_CNT_STRIDE + qb + 1) * 4);  // counts, overflow flags, any-overflow: one memset
+    w.ovf = w.buf_cnt + qb * DENSE_CNT_STRIDE;
+    w.any_ovf = w.ovf + qb;
+    w.buf_doc = (int32_t *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
+    w.buf_score = (float *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
+    w.bytes = (int64_t)(p - (char *)base) + 256;
+    return w;
+}
 }  // namespace
 
 SRX_API int64_t srx_dense_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
     if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_workspace_bytes: bad argument%s");
-    const int qb = nq < DENSE_QB ? nq : DENSE_QB;
-    const int64_t ld = (n_docs + 63) / 64 * 64;
-    const int ns = dense_splits(n_docs, qb, k);
-    return (int64_t)qb * ld * 4 + (int64_t)qb * ns * k * 8 + (int64_t)qb * ns * 4 + 1024;
+    return dense_ws(nullptr, nq, n_docs, k).bytes;
 }
 
 SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
@@ -2254,41 +2418,75 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
     const int qbmax = nq < DENSE_QB ? nq : DENSE_QB;
     const int64_t ld = (n_docs + 63) / 64 * 64;
     const int ns = dense_splits(n_docs, qbmax, k);
-    float *scores = (float *)workspace;
-    int32_t *cand_doc = (int32_t *)(scores + (int64_t)qbmax * ld);
-    float *cand_score = (float *)(cand_doc + (int64_t)qbmax * ns * k);
-    int32_t *cand_count = (int32_t *)(cand_score + (int64_t)qbmax * ns * k);
-    const unsigned gblocks = (unsigned)((n_docs + 32 * WAVES - 1) / (32 * WAVES));
+    const int64_t S = dense_sample(n_docs, k);
+    const DenseWs w = dense_ws(workspace, nq, n_docs, k);
+    auto blocks_for = [](int64_t docs) { return (unsigned)((docs + 32 * WAVES - 1) / (32 * WAVES)); };
+    int ks_ok = 1;
+    // KERNEL<KS> dispatch on dim / 32
+#define SRX_DENSE_DISPATCH(KERNEL, GRID, ...)                                                                         \
+    switch (dim / 32) {                                                                                               \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 24: hipLaunchKernelGGL(KERNEL<24>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        default: ks_ok = 0;                                                                                           \
+    }
     for (int q0 = 0; q0 < nq; q0 += DENSE_QB) {
         const int qb = nq - q0 < DENSE_QB ? nq - q0 : DENSE_QB;
         const int8_t *qp = queries + (int64_t)q0 * dim;
         const float *qs = query_scale + q0;
-#define SRX_DENSE_LAUNCH(KSV)                                                                                             \
-    hipLaunchKernelGGL(srx_dense_i8_scores_kernel<KSV>, dim3(gblocks), dim3(THREADS), 0, stream, corpus, corpus_scale, n_docs, \
-                       qp, qs, qb, scores, ld)
-        switch (dim / 32) {
-            case 1: SRX_DENSE_LAUNCH(1); break;
-            case 2: SRX_DENSE_LAUNCH(2); break;
-            case 3: SRX_DENSE_LAUNCH(3); break;
-            case 4: SRX_DENSE_LAUNCH(4); break;
-            case 6: SRX_DENSE_LAUNCH(6); break;
-            case 8: SRX_DENSE_LAUNCH(8); break;
-            case 12: SRX_DENSE_LAUNCH(12); break;
-            case 16: SRX_DENSE_LAUNCH(16); break;
-            case 24: SRX_DENSE_LAUNCH(24); break;
-            case 32: SRX_DENSE_LAUNCH(32); break;
-            default: return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be 32, 64, 96, 128, 192, 256, 384, 512, 768 or 1024 (pad the rows with zeros)%s");
+        int32_t *od = out_doc + (int64_t)q0 * k;
+        float *os = out_score + (int64_t)q0 * k;
+        int32_t *oc = out_count + q0;
+        const int *no_gate = nullptr;
+        if (S > 0) {
+            // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
+            HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(S), corpus, corpus_scale, S, qp, qs, qb, w.scores, ld, no_gate);
+            if (!ks_ok) break;
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
+                               0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
+                               w.cand_score, w.cand_count, w.tau);
+            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.tau,
+                               DENSE_CAP, doc_base, w.buf_doc, w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
+                               n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, w.ovf, -1, no_gate, w.cand_doc,
+                               w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            int rc = merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, 1, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                                (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
+            if (rc != SRX_OK) return rc;
+            // ---- fallback for queries whose buffer overflowed (degenerate score distributions): through the score
+            //      matrix; both kernels return at once unless the any-overflow flag is set ----
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.scores, ld,
+                               (const int *)w.any_ovf);
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
+                               qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
+                               (const int *)w.any_ovf, w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            rc = merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                            (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
+            if (rc != SRX_OK) return rc;
+        } else {
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.scores, ld, no_gate);
+            if (!ks_ok) break;
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
+                               qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
+                               w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            const int rc = merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                                      (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
+            if (rc != SRX_OK) return rc;
         }
-#undef SRX_DENSE_LAUNCH
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb,
-                           k, ns, doc_base, cand_doc, cand_score, cand_count);
-        HIP_TRY(hipGetLastError());
-        const int rc = merge_impl(device, cand_doc, cand_score, cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1,
-                                  out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_count + q0, (int64_t)k, (int64_t)1,
-                                  nullptr, 0, stream_v);
-        if (rc != SRX_OK) return rc;
     }
+#undef SRX_DENSE_DISPATCH
+    if (!ks_ok) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be 32, 64, 96, 128, 192, 256, 384, 512, 768 or 1024 (pad the rows with zeros)%s");
     return SRX_OK;
 }
 

@@ -57,8 +57,9 @@ def _rand_case(rng, n_docs, dim, nq):
 @pytest.mark.gpu
 def test_dense_int8_matches_oracle_bit_exact():
     rng = np.random.default_rng(77)
+    # small corpora take the score-matrix path; >= 65 536 docs the filtered path (sample threshold + fused filter)
     for n_docs, dim, nq, k in ((1000, 32, 5, 10), (4133, 96, 33, 100), (20_000, 384, 70, 7), (777, 48, 3, 1000), (50_000, 768, 260, 100),
-                               (130, 1024, 64, 128)):
+                               (130, 1024, 64, 128), (150_001, 64, 300, 100), (90_000, 128, 17, 1000)):
         c, cs, q, qs = _rand_case(rng, n_docs, dim, nq)
         if n_docs > 1000:
             c[5] = c[6]  # exact score ties
@@ -105,3 +106,23 @@ def test_dense_int8_reference_fixture_end_to_end(dense_golden):
             for did, sc in exp.items():
                 if list(exp.values()).count(sc) == 1:
                     assert list(got[qid])[list(exp.values()).index(sc)] == did
+
+
+@pytest.mark.gpu
+def test_dense_int8_candidate_overflow_falls_back():
+    """Degenerate score distributions (every doc identical: all scores tie at the threshold) overflow the filtered path's
+    candidate buffers; those queries are re-ranked through the score matrix and the result is still exact -- mixed
+    with queries that do not overflow."""
+    rng = np.random.default_rng(5)
+    n_docs, dim, nq, k = 70_000, 32, 6, 50
+    c = np.tile(rng.integers(1, 100, (1, dim)).astype(np.int8), (n_docs, 1))
+    cs = np.ones(n_docs, np.float32)
+    c[::7] = rng.integers(-127, 128, (len(c[::7]), dim)).astype(np.int8)  # some variety: not every query overflows
+    q = rng.integers(-127, 128, (nq, dim)).astype(np.int8)
+    q[0] = 1
+    q[3] = np.abs(q[3])  # positive queries: tens of thousands of identical positive scores
+    qs = np.full(nq, 1.0 / 127, np.float32)
+    ix = sparse_rx.DenseInt8Index(c, cs)
+    d, s, n = ix.search(q, qs, k)
+    ed, es, en = np_oracle.dense_topk(np_oracle.int8_similarities(q, c, qs, cs), k)
+    assert np.array_equal(n, en) and np.array_equal(s.view(np.uint32), es.view(np.uint32)) and np.array_equal(d, ed)
