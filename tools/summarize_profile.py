@@ -9,7 +9,7 @@ out = f"gpurun_out/prof_{tag}"
 
 
 def short(kn):
-    for n in ("srx_wave_kernel", "srx_score_kernel", "srx_merge_kernel"):
+    for n in ("srx_wave_kernel", "srx_score_kernel", "srx_merge_wave_kernel", "srx_merge_kernel"):
         if n in kn:
             return n
     return None
