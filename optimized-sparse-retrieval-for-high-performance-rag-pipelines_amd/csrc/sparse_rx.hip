@@ -81,9 +81,9 @@ constexpr int EMPTY_KEY = -1;
 constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 #ifndef SRX_W_R
-#define SRX_W_R 12
+#define SRX_W_R 16
 #endif
-constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8 or 12)
+constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8, 12 or 16)
 constexpr int W_WAVES_PER_EU = W_R <= 8 ? 4 : 3;  // what the register budget of that choice allows
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_DUPCAP = 48;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
@@ -1457,9 +1457,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
             } else if (__ballot(lenc > 0) != 0ull) {
                 bool fine;
                 bool done = false;
+                if constexpr (W_R > 12) {
+                    if (__ballot(lenc - 4 * jl > 12 * LPT) != 0ull) {  // uniform: the fourth load step holds postings
+                        fine = process(IntC<16>{}, su, lenc, d, v);
+                        done = true;
+                    }
+                }
                 if constexpr (W_R > 8) {
-                    if (__ballot(lenc - 4 * jl > 8 * LPT) != 0ull) {  // uniform: the third load step holds postings
-                        fine = process(IntC<W_R>{}, su, lenc, d, v);
+                    if (!done && __ballot(lenc - 4 * jl > 8 * LPT) != 0ull) {  // uniform: the third load step holds postings
+                        fine = process(IntC<12>{}, su, lenc, d, v);
                         done = true;
                     }
                 }
