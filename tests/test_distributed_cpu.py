@@ -65,7 +65,7 @@ def _worker(rank, world, port, mode, ret):
     import sparse_rx
     from sparse_rx import synth
     c = synth.zipf_corpus_np(4001, 300, 25, seed=5)  # same corpus on every rank; each uses its own row range
-    q = synth.queries_np(24, c.vocab, 5, seed=6, dist="zipf")
+    q = synth.queries_np(25, c.vocab, 5, seed=6, dist="zipf")  # not a multiple of the world sizes: padded query blocks
     k = 20
     a, b = sparse_rx.shard_range(c.n_docs, world, rank)
     lo, hi = c.indptr[a], c.indptr[b]
