@@ -2138,6 +2138,24 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate counters: one 128-byte line each (all waves
                                       // add to these: counters sharing a line serialise in one L2 channel)
 
+// Query batch in MFMA-fragment order: apack[(tile * KS + s) * 64 + lane] = the 16 bytes lane `lane` feeds into k-step s
+// of query tile `tile` (row tile * 32 + (lane & 31), columns 32 s + 16 (lane >> 5) ..).  A wave's A load is then one
+// contiguous 1 KiB block instead of 32 scattered 32-byte segments (the request rate of the texture path was the limit).
+__global__ __launch_bounds__(THREADS) void srx_dense_pack_queries_kernel(const int8_t *__restrict__ queries, int nq, int dim,
+                                                                         v4i *__restrict__ apack) {
+    const int ks = dim / 32;
+    const int64_t n = (int64_t)((nq + 31) / 32) * ks * 64;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const int lane = (int)(i & 63);
+        const int64_t ts = i >> 6;
+        const int s = (int)(ts % ks);
+        const int q = (int)(ts / ks) * 32 + (lane & 31);
+        v4i x = {0, 0, 0, 0};
+        if (q < nq) x = *reinterpret_cast<const v4i *>(queries + (int64_t)q * dim + s * 32 + 16 * (lane >> 5));
+        apack[i] = x;
+    }
+}
+
 // One wave = 32 docs x (all queries, 32 at a time); a workgroup = 4 waves = 128 consecutive docs.  The wave keeps its
 // docs' B fragments in registers for the whole query loop (KS k-steps of 32: lane l holds corpus[d0 + (l & 31)]
 // [32 s + 16 (l >> 5) .. + 15], one 16-byte load); the queries' A fragments (the same map on the query rows) stream
@@ -2145,7 +2163,7 @@ constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate cou
 template <int KS>
 __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
-                                                                       int64_t n_docs, const int8_t *__restrict__ queries,
+                                                                       int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
                                                                        float *__restrict__ scores, int64_t ld,
                                                                        const int *__restrict__ gate) {
@@ -2168,8 +2186,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            v4i A = {0, 0, 0, 0};
-            if (qa < nq) A = *reinterpret_cast<const v4i *>(queries + (int64_t)qa * DIM + s * 32 + 16 * h);
+            const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
         }
         // the tile's 32 query scales: one coalesced load, then a lane permute per accumulator row (a global load per
@@ -2191,7 +2208,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 template <int KS>
 __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
-                                                                       int64_t n_docs, const int8_t *__restrict__ queries,
+                                                                       int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
                                                                        const unsigned *__restrict__ tau, int cap,
                                                                        int64_t doc_base, int32_t *__restrict__ buf_doc,
@@ -2216,8 +2233,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            v4i A = {0, 0, 0, 0};
-            if (qa < nq) A = *reinterpret_cast<const v4i *>(queries + (int64_t)qa * DIM + s * 32 + 16 * h);
+            const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
         }
         // Survivors of the 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator registers
@@ -2343,7 +2359,15 @@ __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__
     }
 }
 
-constexpr int DENSE_QB = 256;     // queries per pass: bounds the score matrix in the workspace (256 x n_docs x 4 B)
+// Queries per pass: as many as keep the fallback's score matrix (queries x n_docs x 4 B) within 4 GiB, 32 .. 1024.
+// More queries per pass = the docs' B fragments are loaded once for more query tiles.
+int dense_qb(int64_t n_docs) {
+    int64_t q = (4ll << 30) / (((n_docs + 63) / 64 * 64) * 4);
+    q = q / 32 * 32;
+    if (q < 32) q = 32;
+    if (q > 1024) q = 1024;
+    return (int)q;
+}
 constexpr int DENSE_CAP = 65536;  // candidate buffer entries per query of the filtered path
 int dense_splits(int64_t n_docs, int nq, int k) {
     int64_t s = 2048 / (nq > 0 ? nq : 1);  // >= 2048 workgroups when the batch is small
@@ -2371,10 +2395,12 @@ struct DenseWs {
     int *buf_cnt, *ovf, *any_ovf;
     int32_t *buf_doc;
     float *buf_score;
+    v4i *apack;
     int64_t bytes;
 };
 DenseWs dense_ws(void *base, int nq, int64_t n_docs, int k) {
-    const int qb = nq < DENSE_QB ? nq : DENSE_QB;
+    const int QB = dense_qb(n_docs);
+    const int qb = nq < QB ? nq : QB;
     const int64_t ld = (n_docs + 63) / 64 * 64;
     const int ns = dense_splits(n_docs, qb, k);
     const bool filt = dense_sample(n_docs, k) > 0;
@@ -2395,6 +2421,7 @@ DenseWs dense_ws(void *base, int nq, int64_t n_docs, int k) {
     w.any_ovf = w.ovf + qb;
     w.buf_doc = (int32_t *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
     w.buf_score = (float *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
+    w.apack = (v4i *)take((int64_t)((qb + 31) / 32) * 32 * 1024);  // dim <= 1024 bytes per query row
     w.bytes = (int64_t)(p - (char *)base) + 256;
     return w;
 }
@@ -2421,7 +2448,8 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
     if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_i8: workspace too small%s");
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_v;
-    const int qbmax = nq < DENSE_QB ? nq : DENSE_QB;
+    const int QB = dense_qb(n_docs);
+    const int qbmax = nq < QB ? nq : QB;
     const int64_t ld = (n_docs + 63) / 64 * 64;
     const int ns = dense_splits(n_docs, qbmax, k);
     const int64_t S = dense_sample(n_docs, k);
@@ -2443,23 +2471,24 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
         case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
         default: ks_ok = 0;                                                                                           \
     }
-    for (int q0 = 0; q0 < nq; q0 += DENSE_QB) {
-        const int qb = nq - q0 < DENSE_QB ? nq - q0 : DENSE_QB;
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        const int qb = nq - q0 < QB ? nq - q0 : QB;
         const int8_t *qp = queries + (int64_t)q0 * dim;
         const float *qs = query_scale + q0;
         int32_t *od = out_doc + (int64_t)q0 * k;
         float *os = out_score + (int64_t)q0 * k;
         int32_t *oc = out_count + q0;
         const int *no_gate = nullptr;
+        hipLaunchKernelGGL(srx_dense_pack_queries_kernel, dim3(64), dim3(THREADS), 0, stream, qp, qb, (int)dim, w.apack);
         if (S > 0) {
             // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
             HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(S), corpus, corpus_scale, S, qp, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(S), corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
                                w.cand_score, w.cand_count, w.tau);
-            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.tau,
+            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.tau,
                                DENSE_CAP, doc_base, w.buf_doc, w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
                                n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, w.ovf, -1, no_gate, w.cand_doc,
@@ -2470,7 +2499,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             if (rc != SRX_OK) return rc;
             // ---- fallback for queries whose buffer overflowed (degenerate score distributions): through the score
             //      matrix; both kernels return at once unless the any-overflow flag is set ----
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.scores, ld,
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld,
                                (const int *)w.any_ovf);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
@@ -2480,7 +2509,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
                             (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
             if (rc != SRX_OK) return rc;
         } else {
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, qp, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
