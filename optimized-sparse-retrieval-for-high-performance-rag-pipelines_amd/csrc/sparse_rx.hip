@@ -1857,7 +1857,7 @@ Plan make_plan(const srx_index *ix, int nq, int k) {
     if (tpu > MAX_TPS) tpu = MAX_TPS;
     p.tpu = tpu;
     p.n_super = (int)((d.n_tiles + tpu - 1) / tpu);
-    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 4096;  // wave-sized workgroups (256 CUs x 12 waves resident; measured best on 1 k-query batches)
+    const int target = ix->opts.target_blocks > 0 ? ix->opts.target_blocks : 3072;  // wave-sized workgroups: 256 CUs x 12 resident waves = one full round (C2, 1 k queries: 3 splits 0.088 ms, 4 splits 0.094 ms)
     int ns = target / (nq > 0 ? nq : 1);
     if (ns < 1) ns = 1;
     if (ns > p.n_super) ns = p.n_super;
