@@ -141,7 +141,9 @@ def test_uniform_sparse_hash_path(rx):
     for ut in (1, 3, 5, 7):  # units of a non-power-of-two number of tiles
         ix.set_opts(unit_tiles=ut)
         _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), f"uniform unit_tiles={ut}")
-    for sl, tb, dbg in ((0, 0, 0), (12, 0, 0), (16, 1, 0), (14, 100000, 0), (0, 0, 8), (17, 0, 8), (18, 0, 0)):
+    # target_blocks below the batch size: whole rounds of unsplit queries + a tail cut into 2 / 3 / 4 splits
+    for sl, tb, dbg in ((0, 0, 0), (12, 0, 0), (16, 1, 0), (14, 100000, 0), (0, 0, 8), (17, 0, 8), (18, 0, 0), (0, 100, 0), (0, 60, 0),
+                        (12, 250, 0), (0, 60, 8)):
         ix.set_opts(supertile_log2=sl, target_blocks=tb, debug=dbg)  # debug=8: everything through the tier-2 block kernel
         for k in (100, 10, 128, 129):
             _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"uniform sl={sl} tb={tb} dbg={dbg} k={k}")
@@ -157,10 +159,10 @@ def test_zipf_dense_and_overflow_paths(rx):
     assert idf.min() < 0 and df.max() > 0.9 * c.n_docs
     q = synth.queries_np(96, c.vocab, 8, seed=5, dist="zipf")
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=14)
-    for sl, dbg in ((0, 0), (14, 0), (17, 0), (15, 8)):
-        ix.set_opts(supertile_log2=sl, debug=dbg)
+    for sl, dbg, tb in ((0, 0, 0), (14, 0, 0), (17, 0, 0), (15, 8, 0), (0, 0, 40), (14, 0, 90)):  # tb: mixed unsplit / split queries
+        ix.set_opts(supertile_log2=sl, debug=dbg, target_blocks=tb)
         for k in (100, 1000, 1):
-            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf sl={sl} dbg={dbg} k={k}")
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf sl={sl} dbg={dbg} tb={tb} k={k}")
     ix.close()
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=10)  # small tiles: overflow packer groups several tiles per unit
     ix.set_opts(supertile_log2=16)
