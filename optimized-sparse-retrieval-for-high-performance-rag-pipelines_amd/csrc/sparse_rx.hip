@@ -2245,70 +2245,86 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                                                                        float *__restrict__ buf_score,
                                                                        int *__restrict__ buf_cnt, int *__restrict__ ovf,
                                                                        int *__restrict__ any_ovf) {
+    // DT doc tiles of 32 per wave: with two, every A fragment (query tile) read from L2 feeds two MFMAs; the B
+    // fragments of both tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
+    constexpr int DT = KS <= 12 ? 2 : 1;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (32 * DT);
     if (d0 >= n_docs) return;
     constexpr int DIM = KS * 32;
-    const int64_t d = d0 + r;
-    const bool dok = d < n_docs;
-    v4i B[KS];
+    v4i B[DT][KS];
+    double ds[DT];
+    bool dok[DT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        B[s] = (v4i){0, 0, 0, 0};
-        if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+    for (int t = 0; t < DT; ++t) {
+        const int64_t d = d0 + 32 * t + r;
+        dok[t] = d < n_docs;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            B[t][s] = (v4i){0, 0, 0, 0};
+            if (dok[t]) B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+        }
+        ds[t] = dok[t] ? (double)corpus_scale[d] : 0.0;
     }
-    const double ds = dok ? (double)corpus_scale[d] : 0.0;
     for (int q0 = 0; q0 < nq; q0 += 32) {
         const int qa = q0 + r;
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v16i acc[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][s], acc[t], 0, 0, 0);
         }
-        // Survivors of the 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator registers
-        // are in flight together -- one global round trip per tile instead of one per register with survivors:
-        // scores + pass bits; one atomicAdd per (query row, lane half) with survivors; broadcast the bases and store.
-        float scv[16];
-        unsigned passbits = 0;
         // the tile's 32 query scales and thresholds: one coalesced load each, then a lane permute per accumulator row
         const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
         const unsigned tau_mine = qa < nq ? tau[qa] : 0xFFFFFFFFu;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // differs between the two lane halves
-            const float qsr = __shfl(qs_mine, row);
-            const unsigned taur = (unsigned)__shfl((int)tau_mine, row);
-            scv[reg] = dok ? (float)(((double)acc[reg] * (double)qsr) * ds) : 0.0f;
-            if (q0 + row < nq && scv[reg] > 0.0f && __float_as_uint(scv[reg]) >= taur) passbits |= 1u << reg;
-        }
-        if (__ballot(passbits != 0u) != 0ull) {  // uniform; about 6 survivors per tile at the design point
-            int basev[16];
+        for (int t = 0; t < DT; ++t) {
+            // Survivors of one 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator
+            // registers are in flight together -- one global round trip per tile instead of one per register with
+            // survivors: scores + pass bits; one atomicAdd per (query row, lane half) with survivors; broadcast the
+            // bases and store.
+            const int64_t d = d0 + 32 * t + r;
+            float scv[16];
+            unsigned passbits = 0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const bool pass = (passbits >> reg) & 1u;
-                const unsigned long long m = __ballot(pass);
-                const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);  // my half's survivors: one query row
-                basev[reg] = 0;
-                if (pass && (mh & ((1u << r) - 1u)) == 0u)  // first survivor of the row reserves room for all of them
-                    basev[reg] = atomicAdd(&buf_cnt[(q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * DENSE_CNT_STRIDE], __popc(mh));
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // differs between the two lane halves
+                const float qsr = __shfl(qs_mine, row);
+                const unsigned taur = (unsigned)__shfl((int)tau_mine, row);
+                scv[reg] = dok[t] ? (float)(((double)acc[t][reg] * (double)qsr) * ds[t]) : 0.0f;
+                if (q0 + row < nq && scv[reg] > 0.0f && __float_as_uint(scv[reg]) >= taur) passbits |= 1u << reg;
             }
+            if (__ballot(passbits != 0u) != 0ull) {  // uniform; about 6 survivors per tile at the design point
+                int basev[16];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const bool pass = (passbits >> reg) & 1u;
-                const unsigned long long m = __ballot(pass);
-                if (m != 0ull) {  // uniform
-                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);
-                    const int base = __shfl(basev[reg], h * 32 + (mh ? __ffs((int)mh) - 1 : 0));
-                    if (pass) {
-                        const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        const int p = base + __popc(mh & ((1u << r) - 1u));
-                        if (p < cap) {
-                            buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d);
-                            buf_score[(int64_t)q * cap + p] = scv[reg];
-                        } else {
-                            ovf[q] = 1;
-                            *any_ovf = 1;
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool pass = (passbits >> reg) & 1u;
+                    const unsigned long long m = __ballot(pass);
+                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);  // my half's survivors: one query row
+                    basev[reg] = 0;
+                    if (pass && (mh & ((1u << r) - 1u)) == 0u)  // first survivor of the row reserves room for all of them
+                        basev[reg] = atomicAdd(&buf_cnt[(q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * DENSE_CNT_STRIDE], __popc(mh));
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool pass = (passbits >> reg) & 1u;
+                    const unsigned long long m = __ballot(pass);
+                    if (m != 0ull) {  // uniform
+                        const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);
+                        const int base = __shfl(basev[reg], h * 32 + (mh ? __ffs((int)mh) - 1 : 0));
+                        if (pass) {
+                            const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                            const int p = base + __popc(mh & ((1u << r) - 1u));
+                            if (p < cap) {
+                                buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d);
+                                buf_score[(int64_t)q * cap + p] = scv[reg];
+                            } else {
+                                ovf[q] = 1;
+                                *any_ovf = 1;
+                            }
                         }
                     }
                 }
@@ -2518,7 +2534,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
                                w.cand_score, w.cand_count, w.tau);
-            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.tau,
+            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (dim / 32 <= 12 ? blocks_for((n_docs + 1) / 2) : blocks_for(n_docs)), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.tau,
                                DENSE_CAP, doc_base, w.buf_doc, w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
                                n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, w.ovf, -1, no_gate, w.cand_doc,
