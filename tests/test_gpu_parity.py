@@ -278,10 +278,13 @@ def test_merge_topk_matches_single_shard(rx):
         qs = (q[0][: nq_sub + 1], q[1][: q[0][nq_sub]], q[2][: q[0][nq_sub]])
         ix = _dev_index(rx, c, idf, avgdl, tile_log2=10)
         qd = [torch.as_tensor(x, device="cuda:0") for x in qs]
-        d, s, n = ix.search_device(*qd, k)
-        rows = ix.search_packed_device(*qd, k)
-        torch.cuda.synchronize()
-        assert torch.equal(rows[:, :k], d) and torch.equal(rows[:, k:2 * k], s.view(torch.int32)) and torch.equal(rows[:, 2 * k], n)
+        for tb in (0, 2, 7):  # 2, 7: more queries than the split target -> unsplit rounds (final rows written by tier 1) + a split tail (merge kernel)
+            ix.set_opts(target_blocks=tb)
+            d, s, n = ix.search_device(*qd, k)
+            rows = ix.search_packed_device(*qd, k)
+            torch.cuda.synchronize()
+            assert torch.equal(rows[:, :k], d) and torch.equal(rows[:, k:2 * k], s.view(torch.int32)) and torch.equal(rows[:, 2 * k], n)
+            _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), tuple(x[: nq_sub] for x in exp), f"packed tb={tb} nq={nq_sub}")
         ix.close()
 
 
