@@ -94,9 +94,12 @@ typedef struct srx_index srx_index;
 /* Search-time tuning knobs; zero-initialise for defaults. */
 typedef struct {
     int32_t supertile_log2; /* docs per unit = 2^supertile_log2 (>= tile_log2); 0 = auto */
-    int32_t target_blocks;  /* workgroups to aim for when splitting a query's doc range; 0 = auto (4096) */
+    int32_t target_blocks;  /* wave-sized work items to aim for (splits of a query / unsplit rounds + split tail); 0 = auto (3072) */
     int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
-    int32_t reserved;       /* debug bits: 8 = route every query through the tier-2 (block) kernel */
+    int32_t reserved;       /* debug bits.  Exact results: 8 = every query through the tier-2 (block) kernel, 16 = ignore
+                             * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only.  Timing
+                             * experiments with WRONG results (bench ablations): 1 / 2 / 64 = skip candidate handling,
+                             * 4 = loads only, 32 = no final ranking. */
     int32_t unit_tiles;     /* docs per unit = unit_tiles * 2^tile_log2 (1..64, need not be a power of two); 0 = auto.
                                Takes precedence over supertile_log2. */
 } srx_search_opts;
