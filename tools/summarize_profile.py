@@ -23,6 +23,13 @@ for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
         if n:
             lines.append(f"kernel_stats {n:18s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f} "
                          f"min_ns={row['MinNs']} max_ns={row['MaxNs']} pct={row['Percentage']}")
+# per-launch durations of the dominant kernel in dispatch order: 3 warm-up, 20 timed, 3 PCIe-inclusive launches
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "srx_wave_kernel" in r["Kernel_Name"]]
+    if len(d) >= 23:
+        timed = d[3:23]
+        lines.append(f"kernel_trace srx_wave_kernel per launch (ms), dispatch order: " + " ".join(f"{x:.3f}" for x in d))
+        lines.append(f"kernel_trace srx_wave_kernel timed launches 4..23: avg_ms={sum(timed) / len(timed):.4f} min_ms={min(timed):.4f} max_ms={max(timed):.4f}")
 pm = collections.defaultdict(dict)
 for f in sorted(glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
@@ -39,8 +46,9 @@ w = pm["srx_wave_kernel"]
 hbm = (2 * w.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024
 lines.append(f"derived srx_wave_kernel hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {hbm:.6g}")
 open(f"profiles/{name}_rocprofv3_summary.txt", "w").write(
-    "# rocprofv3 --kernel-trace --stats, then separate --pmc passes, of: python3 bench.py --steps 5 --warmup 1 "
-    "--no-cpu-baseline  (workload c3, 1 x MI355X; 9 launches per run: 1 warm-up + 5 timed + 3 PCIe-inclusive)\n"
+    "# rocprofv3 --kernel-trace --stats of: python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (26 launches: 3 warm-up + "
+    "20 timed + 3 PCIe-inclusive), then separate --pmc passes of: python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "
+    "(9 launches each); workload c3, 1 x MI355X\n"
     + "\n".join(lines) + "\n")
 json.dump({"c3@1": {"hbm_bytes_per_launch": hbm, "fetch_size_kib": w.get("FETCH_SIZE", 0),
                     "write_size_kib": w.get("WRITE_SIZE", 0),
