@@ -63,6 +63,8 @@ SYMBOLS = {
     "srx_merge_topk_packed_out": (ctypes.c_int, [_I32, _VP, _I32, _I32, _I32, _VP, _VP, _I64, _VP]),
     "srx_dense_workspace_bytes": (_I64, [_I32, _I64, _I32]),
     "srx_dense_search_i8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_dense_f32_workspace_bytes": (_I64, [_I32, _I64, _I32]),
+    "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
     "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),

@@ -2571,6 +2571,92 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
     return SRX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense f32 side: RetrievalService.search_by_vector (rag_system/core/retrieval.py:402-436):
+// similarities = np.dot(embedding_index, query_vector), then the same top-k.  A matvec per query is HBM-bound (the
+// embedding matrix streams once per pass of up to 4 queries): one wave per doc row, the lane's slices of the queries
+// in registers, products summed in ascending column order per lane, then a fixed butterfly across lanes.  The BLAS
+// summation order of the reference is unspecified, so parity is to 1e-4 relative (north_star), not bit-exact.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int F32_QP = 4;    // queries per pass
+constexpr int F32_MAXS = 16; // dim <= 1024 = 16 slices of 64
+
+__global__ __launch_bounds__(THREADS) void srx_dense_f32_scores_kernel(const float *__restrict__ emb, int64_t n_docs, int dim,
+                                                                       const float *__restrict__ queries, int nqp,
+                                                                       float *__restrict__ scores, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int ns = dim >> 6;  // slices of 64 columns (dim is a multiple of 64)
+    float qv[F32_QP][F32_MAXS];
+#pragma unroll
+    for (int q = 0; q < F32_QP; ++q)
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) qv[q][i] = (q < nqp && i < ns) ? queries[(int64_t)q * dim + lane + 64 * i] : 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * WAVES;
+    for (int64_t d = wave; d < n_docs; d += n_waves) {
+        const float *row = emb + d * dim;
+        float r[F32_MAXS];
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) r[i] = i < ns ? row[lane + 64 * i] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < F32_QP; ++q) {
+            if (q < nqp) {  // uniform
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < F32_MAXS; ++i) a = a + r[i] * qv[q][i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o);
+                if (lane == 0) scores[(int64_t)q * ld + d] = a;
+            }
+        }
+    }
+}
+}  // namespace
+
+SRX_API int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_f32_workspace_bytes: bad argument%s");
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, F32_QP, k);
+    return (int64_t)F32_QP * ld * 4 + (int64_t)F32_QP * ns * k * 8 + (int64_t)F32_QP * ns * 4 + 1024;
+}
+
+SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
+                                 int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
+                                 void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: need n_docs > 0, 1 <= k <= 1024%s");
+    if (dim <= 0 || dim % 64 != 0 || dim > 64 * F32_MAXS)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_f32: dim must be a multiple of 64, <= 1024 (pad the rows with zeros)%s");
+    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: doc_base + n_docs must fit int32%s");
+    if (nq == 0) return SRX_OK;
+    if (!emb || !queries || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: null pointer%s");
+    const int64_t need = srx_dense_f32_workspace_bytes(nq, n_docs, k);
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_f32: workspace too small%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, F32_QP, k);
+    float *scores = (float *)workspace;
+    int32_t *cand_doc = (int32_t *)(scores + (int64_t)F32_QP * ld);
+    float *cand_score = (float *)(cand_doc + (int64_t)F32_QP * ns * k);
+    int32_t *cand_count = (int32_t *)(cand_score + (int64_t)F32_QP * ns * k);
+    int64_t blocks = (n_docs + WAVES - 1) / WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    for (int q0 = 0; q0 < nq; q0 += F32_QP) {
+        const int qb = nq - q0 < F32_QP ? nq - q0 : F32_QP;
+        hipLaunchKernelGGL(srx_dense_f32_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, emb, n_docs, (int)dim,
+                           queries + (int64_t)q0 * dim, qb, scores, ld);
+        hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb, k,
+                           ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0,
+                           (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr);
+        HIP_TRY(hipGetLastError());
+        const int rc = merge_impl(device, cand_doc, cand_score, cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1,
+                                  out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_count + q0, (int64_t)k, (int64_t)1,
+                                  nullptr, 0, stream_v);
+        if (rc != SRX_OK) return rc;
+    }
+    return SRX_OK;
+}
+
 #ifdef SRX_STAMP
 // Diagnostic build only: cumulative s_memtime ticks per kernel segment (see STAMP in srx_wave_kernel); resets.
 extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {

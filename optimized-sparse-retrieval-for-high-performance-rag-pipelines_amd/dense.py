@@ -120,3 +120,58 @@ class QuantizedEmbeddingIndex:
         k = min(top_k, len(self.doc_ids))
         d, s, n = self.index.search(np.stack([a for a, _ in qq]), np.array([b for _, b in qq], dtype=np.float32), k)
         return {qid: {self.doc_ids[int(d[i, j])]: float(s[i, j]) for j in range(int(n[i]))} for i, qid in enumerate(qids)}
+
+
+class DenseF32Index:
+    """f32 embedding matrix resident in HBM: the ``embedding_index`` of ``RetrievalService`` (retrieval.py:329-335);
+    ``search`` replaces ``np.dot(self.embedding_index, query_vector)`` + top-k of ``search_by_vector`` (:411-423) for a
+    batch of query vectors (``srx_dense_search_f32``)."""
+
+    def __init__(self, embeddings, device="cuda:0", doc_base: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.SparseRxUnavailable("no HIP device visible: DenseF32Index needs a GPU (there is no CPU fallback)")
+        _capi.lib()
+        self.device = torch.device(device)
+        e = embeddings if isinstance(embeddings, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(embeddings, dtype=np.float32))
+        assert e.dtype == torch.float32 and e.dim() == 2
+        self.n_docs, self.dim = int(e.shape[0]), int(e.shape[1])
+        self.dim_pad = (self.dim + 63) // 64 * 64
+        if self.dim_pad > 1024:
+            raise ValueError(f"embedding dim {self.dim} > 1024 is not supported by the f32 engine")
+        with torch.cuda.device(self.device):
+            self.emb = torch.zeros((self.n_docs, self.dim_pad), dtype=torch.float32, device=self.device)
+            self.emb[:, : self.dim] = e.to(self.device)
+        self.doc_base = int(doc_base)
+        self._ws = None
+
+    def search_device(self, queries, k: int):
+        torch = _torch()
+        if not (1 <= k <= _capi.limits()["max_k"]):
+            raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
+        nq = int(queries.shape[0])
+        L = _capi.lib()
+        with torch.cuda.device(self.device):
+            q = torch.zeros((nq, self.dim_pad), dtype=torch.float32, device=self.device)
+            q[:, : self.dim] = queries
+            out = (torch.empty((nq, k), dtype=torch.int32, device=self.device), torch.empty((nq, k), dtype=torch.float32, device=self.device),
+                   torch.empty((nq,), dtype=torch.int32, device=self.device))
+            if nq == 0:
+                return out
+            need = _capi.check(L.srx_dense_f32_workspace_bytes(nq, self.n_docs, k), "srx_dense_f32_workspace_bytes")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            rc = L.srx_dense_search_f32(self.device.index or 0, _ptr(self.emb), self.n_docs, self.dim_pad, _ptr(q), nq, k, self.doc_base,
+                                        _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(self._ws), self._ws.numel(),
+                                        _stream_ptr(torch, self.device))
+            _capi.check(rc, "srx_dense_search_f32")
+        return out
+
+    def search(self, queries: np.ndarray, k: int):
+        torch = _torch()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        d, s, n = self.search_device(torch.as_tensor(q, device=self.device), k)
+        torch.cuda.synchronize(self.device)
+        return d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()

@@ -98,3 +98,11 @@ def dense_topk(similarities, k):
         out_s[i, : len(d)] = s
         out_n[i] = len(d)
     return out_d, out_s, out_n
+
+
+def f32_similarities(embeddings, queries):
+    """retrieval.py:411: similarities = np.dot(self.embedding_index, query_vector), one column per query.  Evaluated in
+    float64 and rounded: the reference's fp32 BLAS matvec differs from it by its (unspecified) summation order only."""
+    e = np.asarray(embeddings, dtype=np.float32).astype(np.float64)
+    q = np.asarray(queries, dtype=np.float32).astype(np.float64)
+    return (q @ e.T).astype(np.float32)

@@ -126,3 +126,35 @@ def test_dense_int8_candidate_overflow_falls_back():
     d, s, n = ix.search(q, qs, k)
     ed, es, en = np_oracle.dense_topk(np_oracle.int8_similarities(q, c, qs, cs), k)
     assert np.array_equal(n, en) and np.array_equal(s.view(np.uint32), es.view(np.uint32)) and np.array_equal(d, ed)
+
+
+@pytest.mark.gpu
+def test_dense_f32_search_by_vector():
+    """srx_dense_search_f32 against np.dot(embedding_index, query_vector) (retrieval.py:411-423) -- the call the
+    reference makes; its BLAS summation order is unspecified, so: scores within 1e-5 relative of the float64 value
+    (north_star allows 1e-4), ranking correct up to swaps inside that tolerance, only scores > 0, rows padded."""
+    rng = np.random.default_rng(9)
+    for n_docs, dim, nq, k in ((3000, 64, 1, 10), (20_000, 384, 5, 100), (5000, 100, 9, 7), (70_000, 768, 2, 1000), (400, 1024, 3, 500)):
+        emb = rng.standard_normal((n_docs, dim)).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        ix = sparse_rx.DenseF32Index(emb, doc_base=7)
+        kk = min(k, n_docs)
+        d, s, n = ix.search(q, kk)
+        exact = (q.astype(np.float64) @ emb.astype(np.float64).T)
+        blas = np.stack([np.dot(emb, q[i]) for i in range(nq)])  # what the reference computes
+        tol = 1e-5 * np.abs(emb.astype(np.float64)) @ np.abs(q.astype(np.float64)).T  # per (doc, query) bound, [n_docs, nq]
+        for i in range(nq):
+            cnt = int(n[i])
+            pos = np.sort(exact[i][exact[i] > 0])[::-1]
+            assert abs(cnt - min(kk, len(pos))) <= 1  # a score within rounding of 0 may fall on either side
+            docs = d[i, :cnt] - 7
+            assert len(set(docs.tolist())) == cnt and docs.min() >= 0 and docs.max() < n_docs
+            assert np.all(np.abs(s[i, :cnt] - exact[i][docs]) <= tol[docs, i] + 1e-12)
+            assert np.all(np.abs(s[i, :cnt] - blas[i][docs]) <= 2 * tol[docs, i] + 1e-12)
+            assert np.all(s[i, : cnt - 1] >= s[i, 1:cnt])  # ranked
+            if cnt:  # nothing better than the worst returned score was left out (beyond the tolerance)
+                left_out = np.setdiff1d(np.arange(n_docs), docs)
+                if len(left_out) and cnt == kk:
+                    assert exact[i][left_out].max() <= s[i, cnt - 1] + 2 * tol[left_out, i].max()
+            assert np.all(d[i, cnt:] == -1) and np.all(s[i, cnt:] == 0)

@@ -38,3 +38,18 @@ d, s, n = ixs.search(q[:sq].cpu().numpy(), qs[:sq].cpu().numpy(), k)
 ed, es, en = np_oracle.dense_topk(np_oracle.int8_similarities(q[:sq].cpu().numpy(), c[:sd].cpu().numpy(), qs[:sq].cpu().numpy(), cs[:sd].cpu().numpy()), k)
 assert np.array_equal(n, en) and np.array_equal(d, ed) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
 print("sample verified bit-exact against the oracle")
+
+# ---- f32 search_by_vector (one query at a time is the reference's API; a pass takes up to 4) ----
+e = torch.randn((n_docs, dim), generator=g, device=dev)
+fx = sparse_rx.DenseF32Index(e)
+for nqf in (1, 4):
+    qf = torch.randn((nqf, dim), generator=g, device=dev)
+    for _ in range(2):
+        fx.search_device(qf, k)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10):
+        fx.search_device(qf, k)
+    b.record(); torch.cuda.synchronize()
+    msf = a.elapsed_time(b) / 10
+    print(f"dense f32: {n_docs} docs x {dim} dim, {nqf} quer{'y' if nqf == 1 else 'ies'}, k={k}: {msf:.3f} ms, matrix stream {n_docs * fx.dim_pad * 4 / msf / 1e6:.0f} GB/s")
