@@ -13,6 +13,7 @@ What changes underneath: ``search_bm25`` scores the WHOLE query dict as one batc
 from __future__ import annotations
 
 import logging
+import os
 import threading
 import time
 from typing import Dict, List, Optional, Tuple
@@ -147,6 +148,41 @@ class RetrievalService:
         return {ids[int(i)]: float(s) for i, s in zip(idx, sc) if s > 0}  # :292-296
 
     # -- misc -------------------------------------------------------------------------------------------
+    # -- dense side (retrieval.py:320-339, 402-436) ----------------------------------------------------------
+    def set_embeddings(self, embeddings) -> None:
+        """Make a [n_docs, dim] float32 matrix (row i = doc_ids[i]) the ``embedding_index`` and put it on the GPU.  The
+        reference memory-maps ``embedding_path`` with the row count of its document store (``_load_embeddings``,
+        retrieval.py:320-339); the store is out of scope here, so the rows come from the caller or, in
+        :meth:`search_by_vector`, from ``embedding_path`` once ``build_bm25_index`` has fixed ``doc_ids``."""
+        from .dense import DenseF32Index
+        e = np.asarray(embeddings, dtype=np.float32)
+        if e.ndim != 2 or (self.doc_ids and e.shape[0] != len(self.doc_ids)):
+            raise ValueError("embeddings must be [n_docs, dim] with one row per document")
+        self.embedding_index = e
+        self._dense = DenseF32Index(e, device=self.device)
+
+    def search_by_vector(self, query_vector: np.ndarray, k: int = 10, min_score: float = 0.0) -> List[Dict]:
+        """retrieval.py:402-436: ``np.dot(embedding_index, query_vector)`` + top-k on the GPU (``srx_dense_search_f32``),
+        the ``min_score`` cut and the ``[{"doc_id", "score"}]`` result as in the reference.  (The engine only returns
+        scores > 0, so ``min_score`` < 0 does not bring negative scores back.)"""
+        if getattr(self, "_dense", None) is None and self.embedding_path and os.path.exists(str(self.embedding_path)) and self.doc_ids:
+            n = len(self.doc_ids)
+            dim = os.path.getsize(str(self.embedding_path)) // (n * 4)  # retrieval.py:324-328
+            self.set_embeddings(np.memmap(str(self.embedding_path), dtype="float32", mode="r", shape=(n, dim)))
+        if getattr(self, "_dense", None) is None:
+            raise ValueError("No embedding index available")
+        kk = max(1, min(int(k), self._dense.n_docs))
+        d, s, n = self._dense.search(np.asarray(query_vector, dtype=np.float32), kk)
+        results = []
+        for idx, score in zip(d[0, : int(n[0])], s[0, : int(n[0])]):
+            if score < min_score:
+                break
+            if self.doc_ids and idx < len(self.doc_ids):
+                results.append({"doc_id": self.doc_ids[int(idx)], "score": float(score)})
+            elif not self.doc_ids:
+                results.append({"doc_id": str(int(idx)), "score": float(score)})
+        return results
+
     def clear_cache(self) -> None:
         with self.cache_lock:
             self.query_cache.clear()

@@ -158,3 +158,29 @@ def test_dense_f32_search_by_vector():
                 if len(left_out) and cnt == kk:
                     assert exact[i][left_out].max() <= s[i, cnt - 1] + 2 * tol[left_out, i].max()
             assert np.all(d[i, cnt:] == -1) and np.all(s[i, cnt:] == 0)
+
+
+@pytest.mark.gpu
+def test_service_search_by_vector(tmp_path):
+    """RetrievalService.search_by_vector mirror: embeddings given directly or memory-mapped from embedding_path with the
+    row count of doc_ids (retrieval.py:320-339), result list as in :425-436; ValueError without an embedding index."""
+    rng = np.random.default_rng(3)
+    corpus = {f"d{i}": {"text": f"word{i} common"} for i in range(50)}
+    emb = rng.standard_normal((50, 96)).astype(np.float32)
+    qv = rng.standard_normal(96).astype(np.float32)
+    exp = np.dot(emb, qv)
+    order = [i for i in np.argsort(-exp) if exp[i] > 0][:10]
+    svc = sparse_rx.RetrievalService()
+    svc.build_bm25_index(corpus)
+    with pytest.raises(ValueError, match="No embedding index available"):
+        svc.search_by_vector(qv)
+    svc.set_embeddings(emb)
+    got = svc.search_by_vector(qv, k=10)
+    assert [r["doc_id"] for r in got] == [f"d{i}" for i in order]
+    assert np.allclose([r["score"] for r in got], exp[order], rtol=1e-5, atol=1e-6)
+    assert len(svc.search_by_vector(qv, k=10, min_score=float(exp[order[3]]) - 1e-6)) == 4
+    p = tmp_path / "emb.bin"
+    emb.tofile(p)
+    svc2 = sparse_rx.RetrievalService(embedding_path=str(p))
+    svc2.build_bm25_index(corpus)
+    assert [r["doc_id"] for r in svc2.search_by_vector(qv, k=5)] == [f"d{i}" for i in order[:5]]
