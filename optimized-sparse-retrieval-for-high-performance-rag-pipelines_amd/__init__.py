@@ -4,12 +4,12 @@ from . import _capi
 from ._capi import SparseRxError, SparseRxUnavailable, build_library
 from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, merge_topk_device, tokenize
 from .service import RetrievalService
-from .registry import OptimizedBM25Retriever, OptimizedRetriever, RetrieverRegistry, load_index_npz, save_index_npz
+from .registry import OptimizedBM25Retriever, OptimizedRetriever, QuantizedEmbeddingRetriever, RetrieverRegistry, load_index_npz, save_index_npz
 from .dense import DenseF32Index, DenseInt8Index, QuantizedEmbeddingIndex, quantize_symmetric, quantize_query_symmetric
 from .distributed import ShardedSearcher, shard_range, global_df, global_avgdl, global_term_bounds, bm25_idf_from_df
 
 __all__ = ["RetrievalService", "DeviceIndex", "HostIndex", "build_host_index", "encode_queries", "merge_topk_device",
            "tokenize", "build_library", "SparseRxError", "SparseRxUnavailable", "_capi", "ShardedSearcher", "shard_range",
-           "global_df", "global_avgdl", "global_term_bounds", "bm25_idf_from_df", "OptimizedBM25Retriever", "OptimizedRetriever", "RetrieverRegistry",
+           "global_df", "global_avgdl", "global_term_bounds", "bm25_idf_from_df", "OptimizedBM25Retriever", "OptimizedRetriever", "QuantizedEmbeddingRetriever", "RetrieverRegistry",
            "load_index_npz", "save_index_npz", "DenseF32Index", "DenseInt8Index", "QuantizedEmbeddingIndex", "quantize_symmetric",
            "quantize_query_symmetric"]

@@ -178,6 +178,80 @@ def load_index_npz(path) -> HostIndex:
                      doc_ids=[str(d) for d in z["doc_ids"]])
 
 
+class QuantizedEmbeddingRetriever:
+    """Mirror of the reference's dense retriever (retriever_registry.py:358-559) on the HIP engine: the same simulated
+    embeddings (clustered corpus vectors from ``np.random.seed(42)``, query vectors seeded by ``hash(query_text)``), the
+    symmetric INT8 quantization and result dicts, with ``quantized_dot_product_batch`` + top-k replaced by
+    ``srx_dense_search_i8`` (``use_quantization=False``: ``np.dot`` + top-k replaced by ``srx_dense_search_f32``).  All
+    queries of a ``search`` call go to the GPU as one batch."""
+
+    def __init__(self, method: str, model: str, embedding_dim: int = 768, device: str = "cuda:0", **kwargs):
+        self.method = method.lower()
+        self.model_name = model
+        self.embedding_dim = embedding_dim
+        self.use_quantization = kwargs.get("use_quantization", True)
+        self.quantization_method = kwargs.get("quantization_method", "symmetric")
+        if self.use_quantization and self.quantization_method != "symmetric":
+            raise NotImplementedError("only the reference's default symmetric INT8 scheme is built (retriever_registry.py:437-447)")
+        self.device = device
+        self.corpus_embeddings_int8: Optional[np.ndarray] = None
+        self.corpus_scales: Optional[np.ndarray] = None
+        self.corpus_embeddings_fp32: Optional[np.ndarray] = None
+        self.doc_ids: List[str] = []
+        self._index = None
+
+    def synthetic_embeddings(self, num_docs: int) -> np.ndarray:
+        """retriever_registry.py:409-433: cluster centres + 0.1 noise from the legacy NumPy stream seeded with 42, rows
+        normalised; drawn in the reference's order (centres, assignments, then one noise row per document)."""
+        np.random.seed(42)
+        num_clusters = min(50, num_docs // 10)
+        centers = np.random.randn(num_clusters, self.embedding_dim).astype(np.float32)
+        assign = np.random.randint(0, num_clusters, num_docs)
+        noise = np.random.randn(num_docs, self.embedding_dim) * 0.1       # row i = the i-th randn(dim) call of the reference
+        emb = (centers[assign] + noise).astype(np.float32)                 # f32 + f64 -> f64, stored as f32 (:426)
+        norms = np.linalg.norm(emb, axis=1, keepdims=True)
+        return emb / np.maximum(norms, 1e-8)
+
+    def query_embedding_from_seed(self, seed: int) -> np.ndarray:
+        """retriever_registry.py:526-536 after the hash: randn(dim) from the legacy stream, as f32, normalised."""
+        np.random.seed(seed)
+        e = np.random.randn(self.embedding_dim).astype(np.float32)
+        return e / np.linalg.norm(e)
+
+    def _generate_query_embedding(self, query_text: str) -> np.ndarray:
+        return self.query_embedding_from_seed(hash(query_text) % (2 ** 31))  # process-dependent, like the reference's
+
+    def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
+        from .dense import DenseF32Index, DenseInt8Index, quantize_symmetric
+        self.doc_ids = list(corpus.keys())
+        emb = self.synthetic_embeddings(len(corpus))
+        if self.use_quantization:
+            self.corpus_embeddings_int8, self.corpus_scales = quantize_symmetric(emb)
+            self._index = DenseInt8Index(self.corpus_embeddings_int8, self.corpus_scales, device=self.device)
+        else:
+            self.corpus_embeddings_fp32 = emb
+            self._index = DenseF32Index(emb, device=self.device)
+
+    def search(self, queries: Dict[str, str], top_k: int = 10) -> Dict[str, Dict[str, float]]:
+        from .dense import quantize_query_symmetric
+        if self._index is None:
+            raise ValueError("Index not built. Call build_index_from_corpus() first.")
+        results: Dict[str, Dict[str, float]] = {qid: {} for qid in queries}
+        live = [(qid, text) for qid, text in queries.items() if text]
+        if not live:
+            return results
+        embs = [self._generate_query_embedding(text) for _, text in live]
+        k = max(1, min(int(top_k), len(self.doc_ids)))
+        if self.use_quantization:
+            qq = [quantize_query_symmetric(e) for e in embs]
+            d, s, n = self._index.search(np.stack([a for a, _ in qq]), np.array([b for _, b in qq], dtype=np.float32), k)
+        else:
+            d, s, n = self._index.search(np.stack(embs), k)
+        for i, (qid, _) in enumerate(live):
+            results[qid] = {self.doc_ids[int(d[i, j])]: float(s[i, j]) for j in range(int(n[i]))}  # score > 0 only (:515-519)
+        return results
+
+
 class RetrieverRegistry:
     """retriever_registry.py:562-599."""
 
@@ -202,13 +276,15 @@ class RetrieverRegistry:
             return OptimizedBM25Retriever(method=method, model=model, **params)
         if m == "tfidf":
             return OptimizedBM25Retriever(method="tfidf", model=model, k1=1000, b=0, **params)  # :593-595
-        if m in ("dpr", "contriever", "splade"):
-            raise NotImplementedError(f"'{method}' maps to the reference's synthetic INT8 embedding retriever "
-                                      "(retriever_registry.py:358-559), which is outside this build's scope")
+        if m in ("dpr", "contriever", "splade"):  # :588-592
+            p2 = dict(params)
+            embedding_dim = p2.pop("embedding_dim", 768)
+            return QuantizedEmbeddingRetriever(method=method, model=model or f"quantized_{method}", embedding_dim=embedding_dim, **p2)
         if method in cls._retrievers:
             return cls._retrievers[method](**params)
         raise ValueError(f"Unknown retriever method: {method}")
 
     @classmethod
     def list_available(cls):
-        return {"optimized_sparse": ["bm25", "bm25_custom", "tfidf"], "registered_custom": list(cls._retrievers.keys())}
+        return {"optimized_sparse": ["bm25", "bm25_custom", "tfidf"], "quantized_dense": ["dpr", "contriever", "splade"],
+                "registered_custom": list(cls._retrievers.keys())}

@@ -19,6 +19,7 @@ reference produced for them:
   dense_int8.npz/.json ``QuantizedEmbeddingRetriever`` (symmetric INT8): quantized corpus, per-query similarity rows
                        and ``search`` results for recorded embeddings (run with the argument ``dense`` to refresh
                        only these)
+  dense_synth.npz      its simulated corpus / query embedding generators (seeded NumPy streams)
 
 numba is not installed here, so the reference runs its own NumPy / plain-Python fallbacks
 (NUMBA_AVAILABLE=False, retrieval.py:22-33).
@@ -278,6 +279,14 @@ def make_dense_fixture():
             qi8.append(q8)
             qsc.append(qs[0])
         results = {str(k): r.search(qtexts, top_k=k) for k in (5, 20)}
+        # the simulated embedding generators (retriever_registry.py:409-433, 526-536); hash(text) is process-dependent, so
+        # the seed the reference derived from it in THIS process is recorded next to the vector
+        r2 = ref_reg.QuantizedEmbeddingRetriever("dpr", "fixture", embedding_dim=24)
+        syn = r2._generate_synthetic_embeddings(137)
+        qtext = "what is sparse retrieval"
+        qseed = hash(qtext) % (2 ** 31)
+        qsyn = r2._generate_query_embedding(qtext)
+    np.savez_compressed(os.path.join(OUT, "dense_synth.npz"), synthetic_137x24=syn, query_seed=np.int64(qseed), query_24=qsyn)
     np.savez_compressed(os.path.join(OUT, "dense_int8.npz"), emb=emb, qemb=qemb, corpus_int8=r.corpus_embeddings_int8,
                         corpus_scales=r.corpus_scales, query_int8=np.stack(qi8), query_scales=np.array(qsc, dtype=np.float32),
                         similarities=np.stack(sims))

@@ -184,3 +184,41 @@ def test_service_search_by_vector(tmp_path):
     svc2 = sparse_rx.RetrievalService(embedding_path=str(p))
     svc2.build_bm25_index(corpus)
     assert [r["doc_id"] for r in svc2.search_by_vector(qv, k=5)] == [f"d{i}" for i in order[:5]]
+
+
+def test_simulated_embedding_generators_match_reference(golden_dir):
+    """QuantizedEmbeddingRetriever's simulated embeddings (retriever_registry.py:409-433, 526-536) restated: same legacy
+    NumPy streams, bit for bit (constructing the class does not touch the GPU)."""
+    z = np.load(os.path.join(golden_dir, "dense_synth.npz"))
+    r = sparse_rx.QuantizedEmbeddingRetriever("dpr", "fixture", embedding_dim=24)
+    syn = r.synthetic_embeddings(137)
+    assert syn.dtype == np.float32 and np.array_equal(syn.view(np.uint32), z["synthetic_137x24"].view(np.uint32))
+    qe = r.query_embedding_from_seed(int(z["query_seed"]))
+    assert qe.dtype == np.float32 and np.array_equal(qe.view(np.uint32), z["query_24"].view(np.uint32))
+    with pytest.raises(NotImplementedError):
+        sparse_rx.QuantizedEmbeddingRetriever("dpr", "x", quantization_method="asymmetric")
+    assert isinstance(sparse_rx.RetrieverRegistry.create({"type": "dpr", "params": {"embedding_dim": 64}}), sparse_rx.QuantizedEmbeddingRetriever)
+
+
+@pytest.mark.gpu
+def test_quantized_embedding_retriever_end_to_end():
+    """Registry-created dense retriever: build on simulated embeddings, batched search == per-query oracle on the same
+    quantized arrays (INT8 bit-exact; fp32 mode within tolerance of np.dot)."""
+    corpus = {f"doc{i}": {"text": f"t{i}"} for i in range(400)}
+    queries = {"a": "alpha beta", "b": "", "c": "gamma"}
+    r = sparse_rx.RetrieverRegistry.create({"type": "contriever", "params": {"embedding_dim": 96}})
+    r.build_index_from_corpus(corpus)
+    got = r.search(queries, top_k=7)
+    assert got["b"] == {} and set(got) == {"a", "b", "c"}
+    for qid in ("a", "c"):
+        q8, qs = sparse_rx.quantize_query_symmetric(r._generate_query_embedding(queries[qid]))
+        sims = np_oracle.int8_similarities(q8[None, :], r.corpus_embeddings_int8, np.array([qs], np.float32), r.corpus_scales)
+        ed, es, en = np_oracle.dense_topk(sims, 7)
+        assert list(got[qid]) == [r.doc_ids[i] for i in ed[0, : en[0]]]
+        assert [np.float32(v) for v in got[qid].values()] == list(es[0, : en[0]])
+    f = sparse_rx.QuantizedEmbeddingRetriever("dpr", "m", embedding_dim=64, use_quantization=False)
+    f.build_index_from_corpus(corpus)
+    gf = f.search({"a": "alpha beta"}, top_k=5)["a"]
+    exp = np.dot(f.corpus_embeddings_fp32, f._generate_query_embedding("alpha beta"))
+    order = [i for i in np.argsort(-exp) if exp[i] > 0][:5]
+    assert list(gf) == [f.doc_ids[i] for i in order] and np.allclose(list(gf.values()), exp[order], rtol=1e-5, atol=1e-6)
