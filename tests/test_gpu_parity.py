@@ -359,8 +359,9 @@ def test_registry_twin_golden(rx, golden_dir, tmp_path):
                 assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
                                     np.array(list(e.values()), np.float32), k=int(k), label=f"{name} k={k} {qid}")
         r.close()
+    assert isinstance(rx.RetrieverRegistry.create({"type": "dpr"}), rx.QuantizedEmbeddingRetriever)  # retriever_registry.py:588-592
     with pytest.raises(NotImplementedError):
-        rx.RetrieverRegistry.create({"type": "dpr"})
+        rx.RetrieverRegistry.create({"type": "dpr", "params": {"quantization_method": "asymmetric"}})
     with pytest.raises(ValueError):
         rx.RetrieverRegistry.create({"type": "nope"})
     # pipeline twin: bm25 == the service; .npz cache written then reused
