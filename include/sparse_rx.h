@@ -65,8 +65,10 @@ typedef enum {
  *   tile_skip[t*(n_tiles+1) + j]   number of postings of term t with doc < j*G  (so the run of term t
  *                                  inside docs [a*G, b*G) is [term_ptr[t]+skip[a], term_ptr[t]+skip[b]) )
  *   idf[t]                         per-term weight (retrieval.py:189; evaluate_rag_pipeline.py:273-278)
- * Per-posting contribution at query time: (post_val * idf[t]) * q_weight, fp32, summed per doc in
- * ascending term id -- bit-identical to retrieval.py:72 / evaluate_rag_pipeline.py:117.
+ * Per-posting contribution at query time: (post_val * idf[t]) * q_weight, fp32, summed per doc in the order the
+ * query lists its terms.  Ascending term id is the CSR-row order of retrieval.py:72 / evaluate_rag_pipeline.py:117
+ * (bit-identical to them); query-token order reproduces the pipeline twin's NumPy fallback
+ * (evaluate_rag_pipeline.py:436-479).
  */
 typedef struct {
     int32_t device;    /* HIP device ordinal the pointers live on */
@@ -120,8 +122,12 @@ int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int32_t k);
 
 /*
  * Batched scoring + top-k.  Queries are a CSR batch: query q has terms q_term[q_ptr[q] .. q_ptr[q+1])
- * (ascending, unique, in-vocabulary -- OOV terms dropped on the host as retrieval.py:245-249 does) with
- * weights q_weight (> 0; the term count as float, retrieval.py:248).
+ * (unique inside a query, in-vocabulary -- OOV terms dropped on the host as retrieval.py:245-249 does; their
+ * order is the order in which a doc's contributions are added, see srx_index_desc) with weights q_weight
+ * (the term count as float, retrieval.py:248).
+ * PRECONDITIONS, not checked on the device: q_ptr[0] == 0 and q_ptr non-decreasing; 0 <= q_term < vocab (the
+ * kernels index term_ptr / tile_skip / idf / term_bound with it); no term twice in one query.  The host-array entry
+ * point of the Python mirror (DeviceIndex.search) validates them before launching.
  * Outputs, row q: out_doc[q*k + r] = doc_base + local row of rank r, out_score[q*k + r] its fp32 score,
  * r < out_count[q]; rank order = (score descending, doc ascending); only score > 0 (retrieval.py:295);
  * the rest of the row is padded with doc -1 / score 0.

@@ -100,16 +100,26 @@ def build_host_index(corpus: Dict[str, Dict], idf_kind: str = "bm25") -> HostInd
                      vocabulary=vocabulary, doc_ids=doc_ids)
 
 
-def encode_queries(texts: Sequence[str], vocabulary: Dict[str, int]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Query texts -> CSR batch (q_ptr i32, q_term i32 ascending unique, q_weight f32 = term count).
+def encode_queries(texts: Sequence[str], vocabulary: Dict[str, int], order: str = "term") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Query texts -> CSR batch (q_ptr i32, q_term i32 unique per query, q_weight f32 = term count).
     Mirrors retrieval.py:236-252: tokenise, Counter, OOV dropped; a query with no in-vocabulary term gets an
-    empty row (the reference returns {} for it)."""
+    empty row (the reference returns {} for it).
+
+    The engine adds a doc's contributions in the order the query lists its terms, so ``order`` selects which reference
+    call site is reproduced bit for bit: ``"term"`` (ascending term id) is the CSR-row order of ``simd_bm25_score``
+    (retrieval.py:55-72) and of ``_numpy_bm25_score`` (:302); ``"token"`` (first occurrence in the query text) is the
+    ``relevant_terms`` order of the pipeline twin's ``_numpy_score_documents`` (evaluate_rag_pipeline.py:360-370,
+    436-479)."""
+    if order not in ("term", "token"):
+        raise ValueError(f"order must be 'term' or 'token', got {order!r}")
     q_ptr = np.zeros(len(texts) + 1, dtype=np.int32)
     terms: List[np.ndarray] = []
     weights: List[np.ndarray] = []
     for i, text in enumerate(texts):
         cnt = Counter(tokenize(text)) if text else {}
-        pairs = sorted((vocabulary[t], float(c)) for t, c in cnt.items() if t in vocabulary)
+        pairs = [(vocabulary[t], float(c)) for t, c in cnt.items() if t in vocabulary]  # Counter keeps first-occurrence order
+        if order == "term":
+            pairs.sort()
         q_ptr[i + 1] = q_ptr[i] + len(pairs)
         if pairs:
             terms.append(np.fromiter((p[0] for p in pairs), dtype=np.int32, count=len(pairs)))
@@ -354,7 +364,9 @@ class DeviceIndex:
 
     def search_device(self, q_ptr, q_term, q_weight, k: int, out=None):
         """Batched search on device tensors (q_ptr i32[nq+1], q_term i32, q_weight f32).
-        Returns (doc i32[nq,k], score f32[nq,k], count i32[nq]) device tensors; asynchronous on the current stream."""
+        Returns (doc i32[nq,k], score f32[nq,k], count i32[nq]) device tensors; asynchronous on the current stream.
+        Precondition (NOT checked here, the tensors never leave the device): q_ptr starts at 0 and is non-decreasing,
+        0 <= q_term < vocab, no term twice inside a query -- ``validate_queries`` / ``search`` check host batches."""
         torch = _torch()
         nq = q_ptr.numel() - 1
         if not (1 <= k <= _capi.limits()["max_k"]):
@@ -392,10 +404,32 @@ class DeviceIndex:
             _capi.check(rc, "srx_search_packed")
         return out
 
+    def validate_queries(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> None:
+        """Preconditions of ``srx_search`` (include/sparse_rx.h), checked on the host before anything is launched:
+        q_ptr starts at 0 and never decreases, every term id is in [0, vocab), no term occurs twice inside a query
+        (the kernels index term_ptr / tile_skip / idf with the ids and assume one posting per (doc, term))."""
+        q_ptr = np.asarray(q_ptr)
+        q_term = np.asarray(q_term)
+        if q_ptr.ndim != 1 or len(q_ptr) < 1 or int(q_ptr[0]) != 0 or np.any(np.diff(q_ptr) < 0):
+            raise ValueError("q_ptr must start at 0 and be non-decreasing")
+        n = int(q_ptr[-1])
+        if len(q_term) < n or len(q_weight) < n:
+            raise ValueError("q_term / q_weight are shorter than q_ptr[-1]")
+        t = q_term[:n]
+        if n and (int(t.min()) < 0 or int(t.max()) >= self.vocab):
+            raise ValueError(f"q_term out of range [0, {self.vocab})")
+        if n:
+            row = np.repeat(np.arange(len(q_ptr) - 1), np.diff(q_ptr))
+            o = np.lexsort((t, row))
+            if np.any((row[o][1:] == row[o][:-1]) & (t[o][1:] == t[o][:-1])):
+                raise ValueError("a query lists the same term twice (merge duplicates into one weight)")
+
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
-        """Host arrays in, host arrays out (doc, score, count)."""
+        """Host arrays in, host arrays out (doc, score, count).  The batch is validated first (``validate_queries``);
+        ``search_device`` trusts its device tensors."""
         torch = _torch()
         nq = len(q_ptr) - 1
+        self.validate_queries(q_ptr, q_term, q_weight)
         if nq == 0:
             return (np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), np.zeros(0, np.int32))
         dev = self.device

@@ -6,7 +6,9 @@ Mirrors, on the HIP engine, the two other call sites of the reference's hot path
     (``bm25*`` types score with ``simd_bm25_score``, every other type with ``simd_tfidf_score`` and
     idf = log(N/(df+1)), :257-278, :378-399; index cache ``.rag_cache/{method}_index_{hash}.npz``, :189-200, :280-312)
 so that the YAML experiments and ``benchmark_efficiency`` (objects with ``build_index_from_corpus`` + ``search``) run
-unmodified.  The dense / INT8 retriever types of the registry are outside this build's scope and raise.
+unmodified.  The registry's dense types (dpr / contriever / splade) go to the ``QuantizedEmbeddingRetriever`` mirror.
+
+``top_k`` is limited by the engine to 1 .. 1024 after clamping to the corpus size (``ValueError`` otherwise).
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ class _SparseRetrieverBase:
 
     mode = "bm25"
     strip_cache_key = True
+    term_order = "term"  # accumulation order of a doc's contributions (index.encode_queries)
 
     def __init__(self, k1: float, b: float, device: str, tile_log2: int, use_cache: bool = True):
         self.k1, self.b = k1, b
@@ -89,7 +92,7 @@ class _SparseRetrieverBase:
                 keys.append(key)
             pending[key].append(qid)
         if texts:
-            q_ptr, q_term, q_w = encode_queries(texts, self.host.vocabulary)
+            q_ptr, q_term, q_w = encode_queries(texts, self.host.vocabulary, order=self.term_order)
             docs, scores, counts = self.dev.search(q_ptr, q_term, q_w, min(int(top_k), self.host.n_docs))
             for i, key in enumerate(keys):
                 if q_ptr[i + 1] == q_ptr[i]:
@@ -133,12 +136,22 @@ class OptimizedBM25Retriever(_SparseRetrieverBase):
 
 
 class OptimizedRetriever(_SparseRetrieverBase):
-    """evaluate_rag_pipeline.py:162-479: config dict + hardware dict; non-BM25 types use the tf-idf dot product."""
+    """evaluate_rag_pipeline.py:162-479: config dict + hardware dict; non-BM25 types use the tf-idf dot product.
+
+    ``accumulation``: the order in which a doc's per-term contributions are added.  The reference has two answers:
+    its NumPy fallback ``_numpy_score_documents`` (:436-479, what runs wherever numba is absent -- and what the committed
+    fixtures tests/golden/pipeline_small.* were produced with) walks ``relevant_terms`` in QUERY-TOKEN order; its Numba
+    kernels (:57-121) walk the CSR row, i.e. ascending term id.  The two differ in the last fp32 bit on about a quarter
+    of the fixture queries.  Default ``"token"`` reproduces the runnable reference bit for bit; ``"term"`` gives the
+    Numba / ``RetrievalService`` order."""
 
     strip_cache_key = False  # its cache key is f"{query_text}:{top_k}" (:340)
 
     def __init__(self, config: Dict[str, Any], hardware_info: Optional[Dict[str, Any]] = None, device: str = "cuda:0",
-                 tile_log2: int = 14, cache_dir: str = ".rag_cache"):
+                 tile_log2: int = 14, cache_dir: str = ".rag_cache", accumulation: str = "token"):
+        if accumulation not in ("token", "term"):
+            raise ValueError("accumulation must be 'token' or 'term'")
+        self.term_order = accumulation
         params = config.get("params", {}) or {}
         hardware_info = hardware_info or {"memory_gb": 8, "cores": 4}
         super().__init__(params.get("k1", 1.2), params.get("b", 0.75), device, tile_log2,

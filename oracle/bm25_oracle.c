@@ -134,6 +134,44 @@ ORACLE_API int oracle_tfidf_scores_f32(int64_t n_docs, int64_t vocab, const int6
     return 0;
 }
 
+/* The pipeline twin's NumPy fallback (evaluate_rag_pipeline.py:436-479, `_numpy_score_documents`): term-at-a-time
+ * over `relevant_terms`, which is in QUERY-TOKEN order (first occurrence, :360-370), `scores[docs] += term_scores`.
+ * Per doc that is a sequential fp32 sum of its contributions in the GIVEN term order (not ascending term id), so it
+ * can differ from simd_bm25_score in the last bit.  Restated doc-at-a-time: for every doc, the query's terms in the
+ * given order, each looked up in the (sorted) CSR row.  tfidf != 0: contribution (tf*idf)*qw (:472), else BM25
+ * (idf*(num/den))*qw (:455-457, same fp32 operations as retrieval.py:314-316). */
+ORACLE_API int oracle_scores_given_order(int tfidf, int64_t n_docs, int64_t vocab, const int64_t *indptr,
+                                         const int32_t *indices, const float *data, const float *doc_lengths,
+                                         const float *idf, const int32_t *q_term, const float *q_w, int nt,
+                                         double k1, double b, double avgdl, float *scores) {
+    const float k1f = (float)k1, bf = (float)b, omb = (float)(1.0 - b), k1p1 = (float)(k1 + 1.0),
+                avf = (float)avgdl;
+#pragma omp parallel for schedule(static)
+    for (int64_t d = 0; d < n_docs; ++d) {
+        float s = 0.0f;
+        const float norm = tfidf ? 0.0f : k1f * (omb + (bf * doc_lengths[d]) / avf);
+        const int64_t lo0 = indptr[d], hi0 = indptr[d + 1];
+        for (int i = 0; i < nt; ++i) {
+            const int32_t t = q_term[i];
+            if (t < 0 || t >= vocab) continue;
+            int64_t lo = lo0, hi = hi0;
+            while (lo < hi) { /* lower_bound in the sorted row */
+                const int64_t mid = (lo + hi) >> 1;
+                if (indices[mid] < t) lo = mid + 1; else hi = mid;
+            }
+            if (lo < hi0 && indices[lo] == t) {
+                const float tf = data[lo];
+                if (tfidf)
+                    s += (tf * idf[t]) * q_w[i];
+                else
+                    s += (idf[t] * ((tf * k1p1) / (tf + norm))) * q_w[i];
+            }
+        }
+        scores[d] = s;
+    }
+    return 0;
+}
+
 /* ---- fast_topk_selection (retrieval.py:79-92) ------------------------------------------
  * The reference partitions with argpartition(-scores, k) and sorts the k survivors with
  * argsort; the order of equal scores is whatever introselect/quicksort leave behind, i.e.
@@ -203,7 +241,8 @@ ORACLE_API int64_t oracle_topk(const float *scores, int64_t n, int64_t k, int64_
 
 /* ---- batched driver: what search_bm25 does per query (retrieval.py:203-296) minus the
  * Python-side tokenisation, cache and doc-id mapping.  mode 0 = BM25 fp32, 1 = tf-idf dot fp32,
- * 2 = BM25 Numba-like fp64.  Outputs are [nq, k], rank ordered, entries with score <= 0 dropped
+ * 2 = BM25 Numba-like fp64, 3 / 4 = BM25 / tf-idf fp32 accumulated in the GIVEN term order (pipeline twin's
+ * NumPy fallback).  Outputs are [nq, k], rank ordered, entries with score <= 0 dropped
  * (retrieval.py:295), padded with doc -1 / score 0.  This is also the timed CPU baseline: it
  * keeps the reference's cost model (a full CSR scan per query, prange over docs). */
 ORACLE_API int oracle_search_batch(int mode, int64_t n_docs, int64_t vocab, const int64_t *indptr,
@@ -235,6 +274,9 @@ ORACLE_API int oracle_search_batch(int mode, int64_t n_docs, int64_t vocab, cons
         else if (mode == 1)
             rc = oracle_tfidf_scores_f32(n_docs, vocab, indptr, indices, data, idf, qt, qw, nt,
                                          scores);
+        else if (mode == 3 || mode == 4)
+            rc = oracle_scores_given_order(mode == 4, n_docs, vocab, indptr, indices, data, doc_lengths, idf, qt, qw,
+                                           nt, k1, b, avgdl, scores);
         else
             rc = oracle_bm25_scores_f64(n_docs, vocab, indptr, indices, data, doc_lengths, idf, qt,
                                         qw, nt, k1, b, avgdl, scores);

@@ -16,6 +16,14 @@ reference produced for them:
                        through ``simd_tfidf_score`` (pipeline twin) with its idf variant
   registry_small.json  ``OptimizedBM25Retriever`` (registry twin) results on the same text corpus,
                        bm25 and the registry's tfidf setting (k1=1000, b=0)
+  pipeline_small.json  ``OptimizedRetriever`` (pipeline twin, evaluate_rag_pipeline.py:162-479) ``search`` results on the
+                       same text corpus for bm25, bm25_custom (k1=1.6, b=0.8), splade and dpr types (the last two score
+                       with the tf-idf dot product), k = 5 and 50, fresh build and cache-hit build
+  pipeline_small.npz   per-query full score vectors of its ``_numpy_score_documents`` (accumulation in QUERY-TOKEN order,
+                       :436-479) for the bm25 and splade types, with the token-ordered (term, weight) lists
+  ref_cache/*.npz      the ``.rag_cache/{method}_index_{hash}.npz`` files the reference itself wrote
+                       (``_save_cached_index``, :280-296) for the bm25 and splade types -- data files, read with
+                       ``allow_pickle=False``
   dense_int8.npz/.json ``QuantizedEmbeddingRetriever`` (symmetric INT8): quantized corpus, per-query similarity rows
                        and ``search`` results for recorded embeddings (run with the argument ``dense`` to refresh
                        only these)
@@ -248,6 +256,61 @@ def make_registry_fixture(tmp, corpus, queries):
         json.dump(out, f, ensure_ascii=False, indent=0)
 
 
+def make_pipeline_fixture(tmp, corpus, queries):
+    """The pipeline twin: results, token-ordered score vectors, and the index caches it writes."""
+    import re
+    import shutil
+    from collections import Counter
+    cwd = os.getcwd()
+    os.chdir(tmp)  # the module creates .rag_cache/ in the CWD
+    hw = {"memory_gb": 8, "cores": 4}  # its own hard-coded fallback (evaluate_rag_pipeline.py:50-53)
+    out, full = {}, {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        import rag_system.pipeline.evaluate_rag_pipeline as ref_pipe
+        assert ref_pipe.NUMBA_AVAILABLE is False
+        for name, cfg in (("bm25", {"type": "bm25", "params": {"k1": 1.2, "b": 0.75}}),
+                          ("bm25_custom", {"type": "bm25_custom", "params": {"k1": 1.6, "b": 0.8}}),
+                          ("splade", {"type": "splade"}),
+                          ("dpr", {"type": "dpr"})):
+            r = ref_pipe.OptimizedRetriever(cfg, hw)
+            r.build_index_from_corpus(corpus)       # fresh build, writes the cache
+            res = {str(k): r.search(queries, top_k=k) for k in (5, 50)}
+            r2 = ref_pipe.OptimizedRetriever(cfg, hw)
+            r2.build_index_from_corpus(corpus)      # loads the cache the first one wrote (:194-196)
+            res_cached = {str(k): r2.search(queries, top_k=k) for k in (5, 50)}
+            assert res_cached == res, name
+            out[name] = {"k1": r.k1, "b": r.b, "results": res}
+            if name in ("bm25", "splade"):
+                qn, qt, qw, fs = [], [], [], []
+                for qid, text in queries.items():
+                    toks = re.findall(r"\b\w+\b", text.lower()) if text else []
+                    cnt = Counter(toks)
+                    rel = [r.vocabulary[t] for t in cnt if t in r.vocabulary]   # token (first-occurrence) order, :360-370
+                    if not rel:
+                        continue
+                    qtf = np.zeros(len(r.vocabulary), dtype=np.float32)
+                    for t, c in cnt.items():
+                        if t in r.vocabulary:
+                            qtf[r.vocabulary[t]] = c
+                    qn.append(qid)
+                    qt.append(np.array(rel, dtype=np.int32))
+                    qw.append(qtf[rel])
+                    fs.append(np.asarray(r._numpy_score_documents(qtf, rel), dtype=np.float32))
+                ptr = np.zeros(len(qt) + 1, dtype=np.int32)
+                ptr[1:] = np.cumsum([len(t) for t in qt])
+                full[name] = dict(qids=np.array(qn), q_ptr=ptr, q_term=np.concatenate(qt), q_weight=np.concatenate(qw),
+                                  full_scores=np.stack(fs), idf=r.idf, avgdl=np.float64(r.avgdl))
+    os.makedirs(os.path.join(OUT, "ref_cache"), exist_ok=True)
+    for fn in sorted(os.listdir(".rag_cache")):
+        if fn.startswith(("bm25_index_", "splade_index_")):
+            shutil.copy(os.path.join(".rag_cache", fn), os.path.join(OUT, "ref_cache", fn))
+    os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "pipeline_small.npz"),
+                        **{f"{n}_{k}": v for n, d in full.items() for k, v in d.items()})
+    with open(os.path.join(OUT, "pipeline_small.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=0)
+
+
 def make_dense_fixture():
     """dense_int8.npz: embeddings pushed through the reference's QuantizedEmbeddingRetriever (symmetric INT8):
     ``_quantize_embeddings`` -> corpus_int8 / corpus_scales, and the real ``search`` (query quantization, NumPy
@@ -298,10 +361,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dense":  # only the dense fixture (the others stay as committed)
         make_dense_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pipeline":  # only the pipeline-twin fixtures, on the committed text corpus
+        with open(os.path.join(OUT, "text_small.json"), encoding="utf-8") as f:
+            j = json.load(f)
+        with tempfile.TemporaryDirectory() as tmp:
+            make_pipeline_fixture(tmp, j["corpus"], j["queries"])
+        sys.exit(0)
     with tempfile.TemporaryDirectory() as tmp:
         corpus, queries = make_text_fixture(tmp)
         make_csr_fixture(tmp)
         make_registry_fixture(tmp, corpus, queries)
+        make_pipeline_fixture(tmp, corpus, queries)
     make_dense_fixture()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
