@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- batched BM25 top-k throughput of the HIP engine on synthetic corpora (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2] [--no-cpu-baseline]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c1|c4|c5] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path (srx_search: scoring kernel + merge kernel; for N > 1 also the RCCL
-all-gather of per-shard top-k and the final merge) over one resident query batch.  Default workload "c3" is
-the corpus BASELINE.json's targets are quoted on: 10 M docs x 100 k vocab, 100 nnz/doc (10^9 postings, 8 GB of
-postings -- fits one MI355X), 10 k queries x 8 terms, k = 100.  With N ranks the SAME corpus and batch are
-doc-range sharded N ways (global idf / avgdl), i.e. strong scaling, which is what "queries/s at 1/2/4/8 GPUs,
->= 6x at 8" in the north star measures.  "c2" is BASELINE.json configs[1] (1 M x 50 k, 1 k queries).
+A *step* is one pass of the hot path (srx_search: scoring kernels + merge kernel; for N > 1 also the RCCL exchange of
+the per-shard top-k and the final merge) over one query batch resident in HBM.  Default workload "c3" is the corpus
+BASELINE.json's targets are quoted on: 10 M docs x 100 k vocab, 100 nnz/doc (10^9 postings, 8 GB of postings -- fits
+one MI355X), 10 k queries x 8 terms, k = 100.  With N ranks the SAME corpus and batch are doc-range sharded N ways
+(global idf / avgdl), i.e. strong scaling, which is what "queries/s at 1/2/4/8 GPUs, >= 6x at 8" in the north star
+measures.  "c2" is BASELINE.json configs[1] (1 M x 50 k, 1 k queries), "c1" configs[0] (FiQA-shaped text through the
+full build_bm25_index path, k = 10), "c4" / "c5" configs[3] / configs[4].
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- algorithmic posting bytes of one scoring-kernel launch / its average duration, measured with
-                  hipEvents recorded on the search stream around the kernel inside the timed region
-  cpu_baseline -- the oracle (C/OpenMP restatement of the reference's full-CSR-scan scorer + top-k) timed on this
-                  box's host cores on a bounded sample of the same batch; the sample doubles as a parity check.
+Rank 0 prints ONE JSON line (contract in the task statement).  Fields beyond the contract:
+  value / ms_per_step          device-resident: the query batch is in HBM when the timed region starts, results stay there
+  config.pcie_inclusive_qps    the same steps fed from HOST batches (pinned, double-buffered H2D of the query CSR and
+                               D2H of the nq x k result rows on copy streams, overlapped with the search of the next
+                               batch) -- SURVEY.md 8(d)'s "batch wall time incl. H2D and D2H"
+  roofline.achieved / frac     algorithmic bytes of one step / the scoring kernels' time per step (hipEvents recorded on
+                               the search stream around the kernels inside the timed region)  -- the kernel's roofline
+  roofline.batch_achieved / batch_frac       the same bytes / the step's wall time / (8 TB/s x n_gpus)  
+  roofline.pcie_inclusive_frac               the same bytes / the PCIe-inclusive step time
+  roofline.traffic             HBM bytes per launch from the rocprofv3 PMC pass recorded in profiles/traffic.json -- only
+                               when that pass profiled THIS kernel source (sha256 of csrc/sparse_rx.hip), else null
+  cpu_baseline                 the oracle (C/OpenMP restatement of the reference's full-CSR-scan scorer + top-k) timed on
+                               this box's host cores on a bounded sample of the same batch
+Every run checks its GPU results against the oracle on a sample of the timed batch and exits non-zero on a mismatch:
+at N = 1 the sample of the cpu_baseline leg; at N > 1 every rank scores a 32-query sample on its own shard's host CSR,
+rank 0 merges the per-shard lists on the host by (score desc, doc asc) and compares them with the exchanged rows.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,7 +41,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CPU_THREADS = int(os.environ.get("SRX_CPU_THREADS", "16"))  # the 1-GPU box's CPU share
+
+def _cpu_share() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+# CPU-baseline threads: every core this process may run on (OMP_NUM_THREADS = nproc); with N ranks on one
+# node the cores are divided between them.  SRX_CPU_THREADS overrides.
+_WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+CPU_THREADS = int(os.environ.get("SRX_CPU_THREADS", "0")) or max(1, _cpu_share() // max(1, _WORLD))
 os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 
 import numpy as np  # noqa: E402
@@ -38,6 +62,8 @@ WORKLOADS = {
     # name: n_docs, vocab, nnz/doc, n_queries, terms/query, k, seed
     "c3": dict(n_docs=10_000_000, vocab=100_000, nnz_per_doc=100, n_queries=10_000, terms=8, k=100, seed=20253),
     "c2": dict(n_docs=1_000_000, vocab=50_000, nnz_per_doc=50, n_queries=1_000, terms=8, k=100, seed=20252),
+    # BASELINE.json configs[0]: FiQA-shaped synthetic TEXT through the full text path (sizes are the generator's)
+    "c1": dict(n_docs=57_638, vocab=80_000, nnz_per_doc=130, n_queries=100, terms=10, k=10, seed=20251, kind="text"),
     # secondary workloads (BASELINE.json configs[3], configs[4]); single-GPU numbers are reported in DESIGN.md only
     "c4": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20254,
                kind="splade"),
@@ -47,10 +73,55 @@ WORKLOADS = {
     "c5": dict(n_docs=10_000_000, vocab=100_000, nnz_per_doc=100, n_queries=256, terms=8, k=100, seed=20255, kind="zipf"),
 }
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+N_CHECK = 32            # N > 1: queries of the timed batch verified against the per-shard oracle
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_sha() -> str:
+    import sparse_rx
+    with open(sparse_rx._capi.SRC_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def merge_shard_lists(parts, k):
+    """Host merge of per-shard oracle results [(doc i32[n,k] GLOBAL ids, score f32[n,k], count i32[n])] ->
+    (doc, score, count) ranked (score desc, doc asc), padded with -1 / 0: the contract of srx_merge_topk."""
+    n = parts[0][0].shape[0]
+    out_d = np.full((n, k), -1, np.int32)
+    out_s = np.zeros((n, k), np.float32)
+    out_c = np.zeros(n, np.int32)
+    for q in range(n):
+        d = np.concatenate([p[0][q, : p[2][q]] for p in parts])
+        s = np.concatenate([p[1][q, : p[2][q]] for p in parts])
+        order = np.lexsort((d, -s.astype(np.float64)))[:k]
+        out_d[q, : len(order)] = d[order]
+        out_s[q, : len(order)] = s[order]
+        out_c[q] = len(order)
+    return out_d, out_s, out_c
+
+
+def sharded_sample_check(dist_mod, rank, world, host_csr, doc_base, idf_np, avgdl, q_host, k, mode, gpu_rows, n_check=N_CHECK):
+    """N > 1 self-check.  Every rank runs the oracle on ITS shard's host CSR (corpus-wide idf / avgdl) for the first
+    n_check queries of the batch; the per-shard lists are gathered on rank 0, merged on the host and compared with the
+    rows the GPU path returned, bit for bit.  Returns (ok, n_checked) on rank 0, (True, n) elsewhere."""
+    import oracle
+    q_ptr, q_term, q_w = q_host
+    n = int(min(n_check, len(q_ptr) - 1))
+    qs = (q_ptr[: n + 1] - q_ptr[0], q_term[: q_ptr[n]], q_w[: q_ptr[n]])
+    indptr_h, cols_h, tf_h, dl_h = host_csr
+    d, s, c = oracle.search_batch(indptr_h, cols_h, tf_h, dl_h, idf_np, qs[0], qs[1], qs[2], k, 1.2, 0.75, avgdl, native=True, mode=mode)
+    d = np.where(d >= 0, d + doc_base, -1).astype(np.int32)
+    gathered = [None] * world if rank == 0 else None
+    dist_mod.gather_object((d, s, c), gathered, dst=0)
+    if rank != 0:
+        return True, n
+    ed, es, ec = merge_shard_lists(gathered, k)
+    gd, gs, gc = gpu_rows
+    ok = (np.array_equal(gc[:n], ec) and np.array_equal(gd[:n], ed) and np.array_equal(gs[:n].view(np.uint32), es.view(np.uint32)))
+    return bool(ok), n
 
 
 def main():
@@ -66,7 +137,7 @@ def main():
     ap.add_argument("--supertile-log2", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     ap.add_argument("--unit-tiles", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND every oracle check (profiling runs)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="N > 1: how per-shard top-k lists meet")
@@ -75,7 +146,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal on one GPU: run the N > 1 code path (RCCL all-gather + packed merge) with world size 1")
+                    help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,68 +176,86 @@ def main():
         if val:
             w[key] = val
             custom = True
+    kind = w.get("kind", "uniform")
     n_docs, V, k, nq = w["n_docs"], w["vocab"], w["k"], w["n_queries"]
-    chunk_docs = min(synth.CHUNK_DOCS, n_docs)
-    n_chunks = (n_docs + chunk_docs - 1) // chunk_docs
-    assert n_docs % chunk_docs == 0 and n_chunks % world == 0, "corpus must split into equal chunks per rank"
-    my_chunks = range(rank * n_chunks // world, (rank + 1) * n_chunks // world)
-    shard_docs = len(my_chunks) * chunk_docs
-    doc_base = my_chunks[0] * chunk_docs
+    want_check = not args.no_cpu_baseline          # oracle checks (and, at N = 1, the timed CPU baseline)
+    want_cpu = want_check and world == 1 and not args.force_dist
 
-    # ---- query batch: generated on the host FIRST, so that nothing but kernel launches separates the index build
-    #      (GPU busy, clocks up) from the warm-up and timed steps ----
-    kind = w.get("kind", "uniform")
-    if kind == "uniform":
-        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1)
-    elif kind == "zipf":
-        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=1.0)
-    else:
-        q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=w.get("zipf_s", 0.7), weights="learned")
-    # ---- corpus shard on the device (doc-major COO in CSR order), global statistics ---------------------------
     t_build = time.perf_counter()
-    rows_l, cols_l, tf_l, dl_l = [], [], [], []
-    for ci, c in enumerate(my_chunks):
-        kind = w.get("kind", "uniform")
-        gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]
-        r, cc, tf, dl = (gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev, s=w["zipf_s"]) if "zipf_s" in w
-                         else gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev))
-        rows_l.append(r + ci * chunk_docs)
-        cols_l.append(cc)
-        tf_l.append(tf)
-        dl_l.append(dl)
-    rows, cols, tf, dl = torch.cat(rows_l), torch.cat(cols_l), torch.cat(tf_l), torch.cat(dl_l)
-    del rows_l, cols_l, tf_l, dl_l
-    df = torch.bincount(cols, minlength=V)
-    df_local = df.clone()
-    if dist is not None:
-        dist.all_reduce(df)
-        dl_all = torch.empty(n_docs, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(dl_all, dl)
-    else:
-        dl_all = dl
-    kind = w.get("kind", "uniform")
-    avgdl = float(np.mean(dl_all.cpu().numpy()))  # retrieval.py:190 over the WHOLE corpus
-    if kind == "splade":  # learned-sparse dot product: no idf, no length normalisation (simd_tfidf_score with idf == 1)
-        idf_np = np.ones(V, dtype=np.float32)
-        avgdl = 1.0
-    else:
-        idf_np = np.log((n_docs - df.cpu().numpy() + 0.5) / (df.cpu().numpy() + 0.5)).astype(np.float32)  # retrieval.py:189
-    idf = torch.as_tensor(idf_np, device=dev)
-    nnz_local = int(cols.numel())
-
     host_csr = None
-    want_cpu = (not args.no_cpu_baseline) and world == 1  # also in --force-dist rehearsals: verifies the exchange path
-    if want_cpu:
-        indptr = torch.zeros(shard_docs + 1, dtype=torch.int64, device=dev)
-        indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=shard_docs), 0)
-        host_csr = (indptr.cpu().numpy(), cols.cpu().numpy(), tf.cpu().numpy(), dl.cpu().numpy())
-        del indptr
-
-    ix = sparse_rx.DeviceIndex.from_coo(rows, cols, tf, idf, shard_docs, doc_lengths=dl, k1=1.2, b=0.75, avgdl=avgdl,
-                                        device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
-                                        mode="dot" if kind == "splade" else "bm25",
-                                        val_dtype="f16" if kind == "splade" else "f32")
-    del rows, cols, tf  # (no empty_cache(): 288 GB of HBM, and freeing would idle the GPU before the timed region)
+    if kind == "text":
+        # ---- C1: FiQA-shaped text through the reference's host path (tokenise, vocabulary, CSR, idf, avgdl); every
+        #      rank builds the same host index and uploads its own doc range with the corpus-wide statistics ----
+        corpus, queries = synth.fiqa_shaped_text(n_docs=n_docs, vocab=V, mean_doc_len=w["nnz_per_doc"], n_queries=nq,
+                                                 mean_query_len=w["terms"], seed=w["seed"])
+        hi = sparse_rx.build_host_index(corpus)
+        del corpus
+        V = hi.vocab_size
+        q_ptr, q_term, q_w = sparse_rx.encode_queries(list(queries.values()), hi.vocabulary)
+        a, b = sparse_rx.shard_range(n_docs, world, rank)
+        lo, hi_ = int(hi.indptr[a]), int(hi.indptr[b])
+        sub = ((hi.indptr[a: b + 1] - lo).astype(np.int64), hi.indices[lo:hi_], hi.data[lo:hi_], hi.doc_lengths[a:b])
+        shard_docs, doc_base, idf_np, avgdl = b - a, a, hi.idf, hi.avgdl
+        df_local = torch.as_tensor(np.bincount(sub[1], minlength=V), device=dev)
+        nnz_local, nnz_total = len(sub[1]), hi.nnz
+        if want_check:
+            host_csr = sub
+        ix = sparse_rx.DeviceIndex.from_csr(sub[0], sub[1], sub[2], idf_np, doc_lengths=sub[3], k1=1.2, b=0.75, avgdl=avgdl,
+                                            device=dev, doc_base=doc_base, tile_log2=args.tile_log2)
+    else:
+        chunk_docs = min(synth.CHUNK_DOCS, n_docs)
+        n_chunks = (n_docs + chunk_docs - 1) // chunk_docs
+        assert n_docs % chunk_docs == 0 and n_chunks % world == 0, "corpus must split into equal chunks per rank"
+        my_chunks = range(rank * n_chunks // world, (rank + 1) * n_chunks // world)
+        shard_docs = len(my_chunks) * chunk_docs
+        doc_base = my_chunks[0] * chunk_docs
+        # ---- query batch: generated on the host FIRST, so that nothing but kernel launches separates the index build
+        #      (GPU busy, clocks up) from the warm-up and timed steps ----
+        if kind == "uniform":
+            q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1)
+        elif kind == "zipf":
+            q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=1.0)
+        else:
+            q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=w.get("zipf_s", 0.7), weights="learned")
+        # ---- corpus shard on the device (doc-major COO in CSR order), global statistics ---------------------------
+        rows_l, cols_l, tf_l, dl_l = [], [], [], []
+        gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]
+        for ci, c in enumerate(my_chunks):
+            r, cc, tf, dl = (gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev, s=w["zipf_s"]) if "zipf_s" in w
+                             else gen(c, chunk_docs, V, w["nnz_per_doc"], w["seed"], dev))
+            rows_l.append(r + ci * chunk_docs)
+            cols_l.append(cc)
+            tf_l.append(tf)
+            dl_l.append(dl)
+        rows, cols, tf, dl = torch.cat(rows_l), torch.cat(cols_l), torch.cat(tf_l), torch.cat(dl_l)
+        del rows_l, cols_l, tf_l, dl_l
+        df = torch.bincount(cols, minlength=V)
+        df_local = df.clone()
+        if dist is not None:
+            dist.all_reduce(df)
+            dl_all = torch.empty(n_docs, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(dl_all, dl)
+        else:
+            dl_all = dl
+        avgdl = float(np.mean(dl_all.cpu().numpy()))  # retrieval.py:190 over the WHOLE corpus
+        if kind == "splade":  # learned-sparse dot product: no idf, no length normalisation (simd_tfidf_score with idf == 1)
+            idf_np = np.ones(V, dtype=np.float32)
+            avgdl = 1.0
+        else:
+            idf_np = np.log((n_docs - df.cpu().numpy() + 0.5) / (df.cpu().numpy() + 0.5)).astype(np.float32)  # retrieval.py:189
+        idf = torch.as_tensor(idf_np, device=dev)
+        nnz_local = int(cols.numel())
+        nnz_total = int(df.sum().item())
+        if want_check:  # this shard's doc-major CSR on the host: the oracle's input
+            indptr = torch.zeros(shard_docs + 1, dtype=torch.int64, device=dev)
+            indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=shard_docs), 0)
+            host_csr = (indptr.cpu().numpy(), cols.cpu().numpy(), tf.cpu().numpy(), dl.cpu().numpy())
+            del indptr
+        ix = sparse_rx.DeviceIndex.from_coo(rows, cols, tf, idf, shard_docs, doc_lengths=dl, k1=1.2, b=0.75, avgdl=avgdl,
+                                            device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
+                                            mode="dot" if kind == "splade" else "bm25",
+                                            val_dtype="f16" if kind == "splade" else "f32")
+        del rows, cols, tf  # (no empty_cache(): 288 GB of HBM, and freeing would idle the GPU before the timed region)
     ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,
                 unit_tiles=args.unit_tiles)
     if world > 1 and not args.local_bounds:
@@ -180,15 +269,23 @@ def main():
         ix.set_term_bound(combine_term_bounds(ix.fine_bound.unsqueeze(0).expand(args.emulate_world, -1, -1), args.emulate_world))
     build_s = time.perf_counter() - t_build
 
-    # ---- query batch (generated on the host before the corpus was built), resident in HBM before the timed region ----
+    # ---- query batch resident in HBM before the timed region ----
     qp, qt, qw = (torch.as_tensor(x, device=dev) for x in (q_ptr, q_term, q_w))
     out = (torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
            torch.empty((nq,), dtype=torch.int32, device=dev))
-    ix_search = ix.search_device
-    if dist is None:
-        ix.search_device = lambda a, b, c, kk: ix_search(a, b, c, kk, out=out)  # reuse the output tensors every step
+    calls = {"n": 0}  # local searches (kernel-launch groups) issued: with --chunks a step is several of them
+    ix_search, ix_search_packed = ix.search_device, ix.search_packed_device
 
-    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL all-gather of the packed per-shard top-k + merge
+    def counted_search(a, b, c, kk, out_=None):
+        calls["n"] += 1
+        return ix_search(a, b, c, kk, out=out if (dist is None and out_ is None) else out_)  # N = 1: reuse the output tensors
+
+    def counted_search_packed(a, b, c, kk, out_=None):
+        calls["n"] += 1
+        return ix_search_packed(a, b, c, kk, out=out_)
+
+    ix.search_device, ix.search_packed_device = counted_search, counted_search_packed
+    searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL exchange of the packed per-shard top-k + merge
     searcher.force_exchange = args.force_dist
     searcher.mode = args.exchange
     searcher.overlap = not args.no_overlap
@@ -206,6 +303,7 @@ def main():
     ix.profile_read()  # drop warm-up samples
     barrier()
     torch.cuda.synchronize(dev)
+    calls["n"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -213,38 +311,72 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    log(f"[bench] host submit time {1e3 * t_submit / args.steps:.3f} ms/step of {1e3 * elapsed / args.steps:.3f} ms/step")
+    log(f"[bench] rank {rank}: host submit time {1e3 * t_submit / args.steps:.3f} ms/step of {1e3 * elapsed / args.steps:.3f} ms/step")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ix.profile_read()
+    calls_per_step = calls["n"] / max(1, args.steps)
+    ix.search_device, ix.search_packed_device = ix_search, ix_search_packed
 
-    pcie_qps = None
+    # ---- PCIe-inclusive: the same steps fed from host batches through the pinned double-buffered pipeline ----------
+    pcie_qps = pcie_ms = None
     if dist is None:
+        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=2)
+        n_p = max(6, min(args.steps, 40))
+        tickets = []
+        for i in range(2):  # warm-up (pinned buffers touched, streams created)
+            pipe.result(pipe.submit(q_ptr, q_term, q_w))
+        torch.cuda.synchronize(dev)
         t = time.perf_counter()
-        for _ in range(3):
-            ix.search(q_ptr, q_term, q_w, k)  # H2D of the query batch + search + D2H of nq*k results
-        pcie_qps = 3 * nq / (time.perf_counter() - t)
-        log(f"[bench] PCIe-inclusive (host query batch in, host results out): {pcie_qps:,.0f} queries/s")
+        for i in range(n_p):
+            tickets.append(pipe.submit(q_ptr, q_term, q_w))
+            if len(tickets) == 2:
+                pd_, ps_, pc_ = pipe.result(tickets.pop(0))  # host arrays (views of the pinned result slot)
+        while tickets:
+            pd_, ps_, pc_ = pipe.result(tickets.pop(0))
+        pcie_s = (time.perf_counter() - t) / n_p
+        pcie_qps, pcie_ms = nq / pcie_s, pcie_s * 1e3
+        rd, rs, rc_ = (x.cpu().numpy() for x in res)
+        if not args.debug and not (np.array_equal(pd_, rd) and np.array_equal(ps_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(pc_, rc_)):
+            raise SystemExit("PARITY FAILURE: the host-batch pipeline returned rows that differ from the device-resident search")
+        log(f"[bench] PCIe-inclusive (host query batch in, host results out, pinned + double-buffered): {pcie_qps:,.0f} queries/s "
+            f"({pcie_ms:.3f} ms/step vs {1e3 * elapsed / args.steps:.3f} device-resident)")
         ix.profile_read()
+        pipe.close()
 
-    # ---- roofline of the dominant kernel (this rank's scoring kernel) --------------------------------------------
+    # ---- roofline of the dominant kernel (this rank's scoring kernels) --------------------------------------------
     post_bytes = 8 if ix.post_val.dtype == torch.float32 else 6
-    alg_bytes = int(df_local[qt.long()].sum().item()) * post_bytes + nq * k * 8  # sum df_t*(4+4) + k*8
-    # Dominant kernel = the tier-1 wave kernel; the tier-2 block kernel only sees flagged units (none on the uniform
-    # corpora), but its time is kept in the denominator so that no posting byte is counted without its time.
-    score_s = (prof["wave_ms"] + prof["block_ms"]) * 1e-3
+    alg_bytes = int(df_local[qt.long()].sum().item()) * post_bytes + nq * k * 8  # sum df_t*(4+4) + k*8, this shard
+    # Dominant kernel = the tier-1 wave kernel; the tier-2 block kernel's time is kept in the denominator so that no
+    # posting byte is counted without its time.  Per STEP: the per-call averages times the calls one step makes.
+    score_s = (prof["wave_ms"] + prof["block_ms"]) * 1e-3 * calls_per_step
     achieved = alg_bytes / score_s / 1e9
-    traffic = None
+    alg_total = alg_bytes
+    if dist is not None:
+        t = torch.tensor([alg_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        alg_total = int(t.item())
+    step_s = elapsed / args.steps
+    batch_achieved = alg_total / step_s / 1e9
+    traffic, traffic_note = None, "no PMC pass recorded for this workload"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     wl_name = args.workload + ("-custom" if custom else "")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(f"{wl_name}@{world}", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            ent = json.load(open(tpath)).get(f"{wl_name}@{world}")
+            if ent is not None:
+                if ent.get("kernel_src_sha256") == kernel_source_sha():
+                    traffic, traffic_note = ent.get("hbm_bytes_per_launch"), ent.get("note")
+                else:
+                    traffic_note = "the recorded PMC pass profiled a different kernel source (sha256 of csrc/sparse_rx.hip differs); re-run tools/gpu_profile.sh"
+        except Exception as e:  # pragma: no cover
+            traffic_note = f"profiles/traffic.json unreadable: {e}"
+    dominant = {"splade": "srx_score_kernel<__half> (tier 2: k > 128)", "zipf": "srx_score_kernel<float> (tier 2: dense tiles)"}.get(
+        kind, "srx_wave_kernel<float>")
+    if prof["wave_ms"] >= prof["block_ms"]:
+        dominant = "srx_wave_kernel<__half>" if kind == "splade" else "srx_wave_kernel<float>"
 
     result = {
         "metric": "queries/sec + achieved HBM GB/s, batch BM25 top-k=%d" % k,
@@ -253,35 +385,57 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": step_s * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f16" if kind == "splade" else "f32",
         "data": "synthetic",
         "config": {"workload": f"{wl_name}: {n_docs} docs x {V} vocab, {w['nnz_per_doc']} nnz/doc, "
-                               f"{nq}-query batch x {w['terms']} terms, k={k}",
-                   "n_docs": n_docs, "vocab": V, "nnz": nnz_local * world if world > 1 else nnz_local, "n_queries": nq, "k": k,
+                               f"{nq}-query batch x {w['terms']} terms, k={k}; value = device-resident batches "
+                               f"(pcie_inclusive_qps = host batches in / host rows out)",
+                   "n_docs": n_docs, "vocab": V, "nnz": nnz_total, "n_queries": nq, "k": k,
                    "sharding": f"doc-range x{world}" + ((" + RCCL all-to-all of packed per-shard top-k, merge of the own query block, all-gather of merged rows" if args.exchange == "a2a" else " + one RCCL all-gather of packed per-shard top-k") if (world > 1 or args.force_dist) else ""),
-                   "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps},
+                   "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps, "pcie_inclusive_ms_per_step": pcie_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "srx_wave_kernel<float>" if kind != "splade" else "srx_score_kernel<__half> (tier 2: k > 128)",
-                     "kernel_ms": prof["wave_ms"], "tier2_kernel_ms": prof["block_ms"], "merge_kernel_ms": prof["merge_ms"],
-                     "launches_timed": prof["calls"],
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note, "kernel": dominant,
+                     "kernel_ms": prof["wave_ms"] * calls_per_step, "tier2_kernel_ms": prof["block_ms"] * calls_per_step,
+                     "merge_kernel_ms": prof["merge_ms"] * calls_per_step,
+                     "launches_timed": prof["calls"], "launches_per_step": calls_per_step,
+                     "algorithmic_bytes_per_launch": alg_bytes / max(calls_per_step, 1e-9),
+                     "algorithmic_bytes_per_step_all_gpus": alg_total,
+                     "batch_achieved": batch_achieved, "batch_frac": batch_achieved / (HBM_PEAK_GBPS * world),
+                     "pcie_inclusive_frac": (alg_total / (pcie_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if pcie_ms else None},
     }
 
-    # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample; doubles as a parity check ------------------
-    if want_cpu and rank == 0:
+    oracle_mode = None
+    if want_check:
         import oracle
+        oracle_mode = oracle.MODE_TFIDF_F32 if kind == "splade" else oracle.MODE_BM25_F32
+    # ---- N > 1 (and --force-dist rehearsals): per-shard oracle sample, host merge, compare with the exchanged rows --
+    if want_check and dist is not None:
+        gpu_rows = tuple(x.cpu().numpy() for x in res)
+        ok, n_chk = sharded_sample_check(dist, rank, world, host_csr, doc_base, idf_np, avgdl, (q_ptr, q_term, q_w), k, oracle_mode, gpu_rows)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1:
+            if rank == 0:
+                log("PARITY FAILURE: exchanged GPU rows differ from the host merge of the per-shard oracle lists")
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        result["parity_check"] = {"queries": n_chk, "shards": world, "how": "per-shard oracle (full-CSR scan) on each rank's host CSR, "
+                                  "host merge by (score desc, doc asc) on rank 0, bit-exact comparison with the exchanged GPU rows"}
+        result["cpu_baseline"] = None
+    # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample; doubles as the parity check ------------------
+    elif want_cpu and rank == 0:
         indptr_h, cols_h, tf_h, dl_h = host_csr
         gd, gs, gc = (x.cpu().numpy() for x in res)
-        # size the sample: one query first
+
         def run(nsamp):
             qs = (q_ptr[: nsamp + 1] - q_ptr[0], q_term[: q_ptr[nsamp]], q_w[: q_ptr[nsamp]])
             t = time.perf_counter()
             r = oracle.search_batch(indptr_h, cols_h, tf_h, dl_h, idf_np, qs[0], qs[1], qs[2], k, 1.2, 0.75, avgdl, native=True,
-                                    mode=oracle.MODE_TFIDF_F32 if kind == "splade" else oracle.MODE_BM25_F32)
+                                    mode=oracle_mode)
             return time.perf_counter() - t, r
         t1, _ = run(1)   # also warms the page cache / thread pool
         t1, _ = run(1)
@@ -289,14 +443,16 @@ def main():
         tc, (ed, es, ec) = run(nsamp)
         ok = (np.array_equal(gc[:nsamp], ec) and np.array_equal(gd[:nsamp], ed)
               and np.array_equal(gs[:nsamp].view(np.uint32), es.view(np.uint32)))
-        if not ok:
+        if not ok and not args.debug:
             raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
         result["cpu_baseline"] = {"value": nsamp / tc, "unit": "queries/s", "cores": oracle.num_threads(native=True),
-                                  "kind": "port",
+                                  "kind": "port", "nproc": os.cpu_count(), "cpu_share": _cpu_share(),
                                   "sample": f"first {nsamp} queries of the same batch, full-CSR-scan scorer + top-k "
-                                            f"(oracle/bm25_oracle.c, -O3 -march=native, OpenMP), {tc:.1f} s; "
+                                            f"(oracle/bm25_oracle.c, -O3 -march=native, OpenMP, {oracle.num_threads(native=True)} threads "
+                                            f"= the cores this process may use; the host has {os.cpu_count()}), {tc:.1f} s; "
                                             "GPU output for the sample verified bit-exact against it",
                                   "cpu": _cpu_model()}
+        result["parity_check"] = {"queries": nsamp, "shards": 1, "how": "cpu_baseline sample, bit-exact"}
     elif rank == 0:
         result["cpu_baseline"] = None
 

@@ -2,13 +2,13 @@
 ``RetrievalService.build_bm25_index()`` / ``search_bm25()`` API.  Import as ``sparse_rx``."""
 from . import _capi
 from ._capi import SparseRxError, SparseRxUnavailable, build_library
-from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, merge_topk_device, tokenize
+from .index import DeviceIndex, HostBatchPipeline, HostIndex, build_host_index, encode_queries, merge_topk_device, tokenize
 from .service import RetrievalService
 from .registry import OptimizedBM25Retriever, OptimizedRetriever, QuantizedEmbeddingRetriever, RetrieverRegistry, load_index_npz, save_index_npz
 from .dense import DenseF32Index, DenseInt8Index, QuantizedEmbeddingIndex, quantize_symmetric, quantize_query_symmetric
 from .distributed import ShardedSearcher, shard_range, global_df, global_avgdl, global_term_bounds, bm25_idf_from_df
 
-__all__ = ["RetrievalService", "DeviceIndex", "HostIndex", "build_host_index", "encode_queries", "merge_topk_device",
+__all__ = ["RetrievalService", "DeviceIndex", "HostBatchPipeline", "HostIndex", "build_host_index", "encode_queries", "merge_topk_device",
            "tokenize", "build_library", "SparseRxError", "SparseRxUnavailable", "_capi", "ShardedSearcher", "shard_range",
            "global_df", "global_avgdl", "global_term_bounds", "bm25_idf_from_df", "OptimizedBM25Retriever", "OptimizedRetriever", "QuantizedEmbeddingRetriever", "RetrieverRegistry",
            "load_index_npz", "save_index_npz", "DenseF32Index", "DenseInt8Index", "QuantizedEmbeddingIndex", "quantize_symmetric",

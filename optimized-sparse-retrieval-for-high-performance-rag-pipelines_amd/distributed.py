@@ -60,11 +60,18 @@ def global_term_bounds(index, group=None) -> None:
     return fewer than k rows, which is all the final merge can use."""
     import torch
     import torch.distributed as dist
-    from .index import combine_term_bounds
-    if index.fine_bound is None or not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    from .index import DeviceIndex, combine_term_bounds
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return
     world = dist.get_world_size(group)
-    mine = index.fine_bound.contiguous()
+    # The decision to enter the collective must not depend on rank-local state: a shard without a table (no postings,
+    # or a negative stored value in dot mode: DeviceIndex._term_bounds) contributes an all-zero one.  0 is a valid lower
+    # bound of every K-th largest value, the other shards' own maxima stay valid (docs are disjoint across shards), and
+    # a rank that skipped the all-gather would leave the others hanging in it.
+    if index.fine_bound is not None:
+        mine = index.fine_bound.contiguous()
+    else:
+        mine = torch.zeros((index.vocab, len(DeviceIndex.FINE_KS)), dtype=torch.float32, device=index.device)
     g = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(g.view(world * mine.shape[0], mine.shape[1]), mine, group=group)
     index.set_term_bound(combine_term_bounds(g, world))

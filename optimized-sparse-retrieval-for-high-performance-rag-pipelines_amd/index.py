@@ -129,6 +129,34 @@ def encode_queries(texts: Sequence[str], vocabulary: Dict[str, int], order: str 
     return q_ptr, q_term, q_weight
 
 
+def validate_query_batch(q_ptr, q_term, q_weight, vocab: int) -> None:
+    """Preconditions of ``srx_search`` (include/sparse_rx.h), checked on the host before anything is launched:
+    q_ptr starts at 0 and never decreases, every term id is in [0, vocab), no term occurs twice inside a query
+    (the kernels index term_ptr / tile_skip / idf with the ids and assume one posting per (doc, term)).
+    Raises ValueError."""
+    q_ptr = np.asarray(q_ptr)
+    q_term = np.asarray(q_term)
+    if q_ptr.ndim != 1 or len(q_ptr) < 1 or int(q_ptr[0]) != 0 or np.any(np.diff(q_ptr.astype(np.int64)) < 0):
+        raise ValueError("q_ptr must start at 0 and be non-decreasing")
+    n = int(q_ptr[-1])
+    if len(q_term) < n or len(np.asarray(q_weight)) < n:
+        raise ValueError("q_term / q_weight are shorter than q_ptr[-1]")
+    t = q_term[:n]
+    if n and (int(t.min()) < 0 or int(t.max()) >= vocab):
+        raise ValueError(f"q_term out of range [0, {vocab})")
+    if n > 1:
+        # fast path (ascending rows, what encode_queries(order="term") emits): strictly increasing inside every row
+        inc = t[1:] > t[:-1]
+        starts = q_ptr[1:-1]
+        starts = starts[(starts > 0) & (starts < n)]
+        inc[starts - 1] = True  # the step across a row boundary may go down
+        if not inc.all():
+            row = np.repeat(np.arange(len(q_ptr) - 1), np.diff(q_ptr))
+            o = np.lexsort((t, row))
+            if np.any((row[o][1:] == row[o][:-1]) & (t[o][1:] == t[o][:-1])):
+                raise ValueError("a query lists the same term twice (merge duplicates into one weight)")
+
+
 # ---------------------------------------------------------------------------------------------------------
 # device index
 # ---------------------------------------------------------------------------------------------------------
@@ -405,24 +433,7 @@ class DeviceIndex:
         return out
 
     def validate_queries(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> None:
-        """Preconditions of ``srx_search`` (include/sparse_rx.h), checked on the host before anything is launched:
-        q_ptr starts at 0 and never decreases, every term id is in [0, vocab), no term occurs twice inside a query
-        (the kernels index term_ptr / tile_skip / idf with the ids and assume one posting per (doc, term))."""
-        q_ptr = np.asarray(q_ptr)
-        q_term = np.asarray(q_term)
-        if q_ptr.ndim != 1 or len(q_ptr) < 1 or int(q_ptr[0]) != 0 or np.any(np.diff(q_ptr) < 0):
-            raise ValueError("q_ptr must start at 0 and be non-decreasing")
-        n = int(q_ptr[-1])
-        if len(q_term) < n or len(q_weight) < n:
-            raise ValueError("q_term / q_weight are shorter than q_ptr[-1]")
-        t = q_term[:n]
-        if n and (int(t.min()) < 0 or int(t.max()) >= self.vocab):
-            raise ValueError(f"q_term out of range [0, {self.vocab})")
-        if n:
-            row = np.repeat(np.arange(len(q_ptr) - 1), np.diff(q_ptr))
-            o = np.lexsort((t, row))
-            if np.any((row[o][1:] == row[o][:-1]) & (t[o][1:] == t[o][:-1])):
-                raise ValueError("a query lists the same term twice (merge duplicates into one weight)")
+        validate_query_batch(q_ptr, q_term, q_weight, self.vocab)
 
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
         """Host arrays in, host arrays out (doc, score, count).  The batch is validated first (``validate_queries``);
@@ -460,6 +471,95 @@ class DeviceIndex:
             self.close()
         except Exception:
             pass
+
+
+class HostBatchPipeline:
+    """Host batches in, host rows out, with the PCIe copies off the critical path (the metric's batch
+    wall time includes the H2D of the query batch and the D2H of the nq x k results).
+
+    Per slot (``depth`` of them, 2 = double buffering): a pinned host staging buffer and a device buffer for the query
+    CSR (q_ptr | q_term | q_weight packed into one int32 block: ONE H2D copy), a device block of packed result rows
+    [k doc ids][k score bits][count] written directly by ``srx_search_packed`` and a pinned host block for them (ONE
+    D2H copy).  H2D runs on its own HIP stream, the search on the caller's current stream, D2H on a third stream,
+    ordered by events; so while batch i is being scored, batch i+1 is uploading and batch i-1 is downloading.
+    ``submit`` returns a ticket at once; ``result(ticket)`` waits for that batch's D2H and returns NumPy views of the
+    pinned rows (valid until the slot is reused ``depth`` submits later)."""
+
+    def __init__(self, index: "DeviceIndex", max_queries: int, max_terms: int, k: int, depth: int = 2, validate: bool = True):
+        torch = _torch()
+        if not (1 <= k <= _capi.limits()["max_k"]):
+            raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
+        self.index, self.k, self.depth, self.validate = index, int(k), int(depth), validate
+        self.max_queries, self.max_terms = int(max_queries), int(max_terms)
+        dev = index.device
+        qwords = self.max_queries + 1 + 2 * self.max_terms
+        row = 2 * self.k + 1
+        self.slots = []
+        with torch.cuda.device(dev):
+            self.s_in, self.s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            for _ in range(self.depth):
+                self.slots.append({
+                    "h_q": torch.empty(qwords, dtype=torch.int32).pin_memory(), "d_q": torch.empty(qwords, dtype=torch.int32, device=dev),
+                    "d_out": torch.empty((self.max_queries, row), dtype=torch.int32, device=dev),
+                    "h_out": torch.empty((self.max_queries, row), dtype=torch.int32).pin_memory(),
+                    "ev_in": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "ev_out": torch.cuda.Event(), "busy": False, "nq": 0})
+        self._n = 0
+
+    def submit(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> int:
+        torch = _torch()
+        nq, nt = len(q_ptr) - 1, int(q_ptr[-1])
+        if nq > self.max_queries or nt > self.max_terms:
+            raise ValueError("batch larger than the pipeline was sized for")
+        if self.validate:
+            validate_query_batch(q_ptr, q_term, q_weight, self.index.vocab)
+        ticket = self._n
+        s = self.slots[ticket % self.depth]
+        if s["busy"]:
+            raise RuntimeError("slot still holds an unread result: call result() for the ticket submitted `depth` batches ago")
+        hq = s["h_q"].numpy()
+        hq[: nq + 1] = q_ptr
+        hq[nq + 1: nq + 1 + nt] = q_term[:nt]
+        hq[nq + 1 + nt: nq + 1 + 2 * nt].view(np.float32)[:] = q_weight[:nt]
+        dev = self.index.device
+        main = torch.cuda.current_stream(dev)
+        n_words = nq + 1 + 2 * nt
+        with torch.cuda.stream(self.s_in):
+            s["d_q"][:n_words].copy_(s["h_q"][:n_words], non_blocking=True)
+            s["ev_in"].record(self.s_in)
+        main.wait_event(s["ev_in"])
+        dq = s["d_q"]
+        if nq:
+            self.index.search_packed_device(dq[: nq + 1], dq[nq + 1: nq + 1 + nt], dq[nq + 1 + nt: n_words].view(torch.float32),
+                                            self.k, out=s["d_out"][:nq])
+        s["ev_done"].record(main)
+        with torch.cuda.stream(self.s_out):
+            self.s_out.wait_event(s["ev_done"])
+            if nq:
+                s["h_out"][:nq].copy_(s["d_out"][:nq], non_blocking=True)
+            s["ev_out"].record(self.s_out)
+        s["busy"], s["nq"] = True, nq
+        self._n += 1
+        return ticket
+
+    def result(self, ticket: int):
+        """(doc i32[nq,k], score f32[nq,k], count i32[nq]) as NumPy views of the slot's pinned rows."""
+        s = self.slots[ticket % self.depth]
+        if not s["busy"] or ticket < self._n - self.depth:
+            raise RuntimeError("ticket already consumed or overwritten")
+        s["ev_out"].synchronize()
+        s["busy"] = False
+        rows = s["h_out"].numpy()[: s["nq"]]
+        k = self.k
+        return rows[:, :k], rows[:, k:2 * k].view(np.float32), rows[:, 2 * k]
+
+    def search(self, q_ptr, q_term, q_weight):
+        """One batch, synchronously (copies of the result views)."""
+        d, sc, c = self.result(self.submit(q_ptr, q_term, q_weight))
+        return d.copy(), sc.copy(), c.copy()
+
+    def close(self) -> None:
+        _torch().cuda.synchronize(self.index.device)
+        self.slots = []
 
 
 def merge_topk_device(in_doc, in_score, in_count, k: int, gathered: bool = False):

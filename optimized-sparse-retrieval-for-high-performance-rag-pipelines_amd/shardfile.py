@@ -4,13 +4,19 @@ The reference only caches its host-side CSR (``.rag_cache/*.npz``, evaluate_rag_
 ``registry.save_index_npz`` / ``load_index_npz``).  A rank of a 10 M-doc deployment should not redo the CSR -> CSC
 transposition, impacts and skip table at start-up, so the device index itself can be stored:
 
-    magic "SRXSHARD" | u32 version | u32 header_len | header JSON (utf-8) | padding to 4096 |
+    magic "SRXSHARD" | u32 version | u32 header_len | u32 crc32(header JSON) | header JSON (utf-8) | padding to 4096 |
     raw little-endian arrays, each starting at a multiple of 4096: term_ptr i64[V+1], post_doc i32[nnz+PAD],
     post_val f32|f16[nnz+PAD], tile_skip i32[V*(n_tiles+1)], idf f32[V], term_bound f32[V*4] and fine_bound f32[V*14]
     (both optional)
 
-The header carries the dims, dtypes, byte offsets and a CRC-32 of every array.  Loading memory-maps the file and streams
-each array to the GPU in bounded chunks (host memory stays small at 10^9 postings); nothing in the file is executed."""
+The header carries the dims, dtypes, byte offsets and a CRC-32 of every array, and is itself covered by a CRC-32.
+Reading validates the header against itself BEFORE anything reaches the GPU -- the kernels index the arrays with these
+dims and receive raw pointers without sizes, so a damaged or mismatched header must become a ``ValueError`` here, never
+an out-of-bounds device read: every array length against the dims (term_ptr V+1, idf V, postings nnz + pad, skip table
+V x (n_tiles+1), bounds V x 4 / V x 14), term_ptr[0] == 0, term_ptr[V] == nnz and non-decreasing, offsets non-negative,
+aligned and non-overlapping; with ``verify`` also the array checksums, doc ids inside [0, n_docs) and the skip rows
+(non-decreasing, ending at the term's posting count).  Loading memory-maps the file and streams each array to the GPU in
+bounded chunks (host memory stays small at 10^9 postings); nothing in the file is executed."""
 import json
 import os
 import struct
@@ -20,7 +26,7 @@ from typing import Dict
 import numpy as np
 
 MAGIC = b"SRXSHARD"
-VERSION = 1
+VERSION = 2
 ALIGN = 4096
 _ARRAYS = ("term_ptr", "post_doc", "post_val", "tile_skip", "idf", "term_bound", "fine_bound")
 _DTYPES = {"int64": np.int64, "int32": np.int32, "float32": np.float32, "float16": np.float16}
@@ -48,12 +54,12 @@ def write_shard_file(path: str, arrays: Dict[str, np.ndarray], meta: Dict) -> No
         off += (a.nbytes + ALIGN - 1) // ALIGN * ALIGN
     header = json.dumps({"meta": {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in meta.items()},
                          "arrays": entries}, sort_keys=True).encode("utf-8")
-    pre = len(MAGIC) + 8 + len(header)
+    pre = len(MAGIC) + 12 + len(header)
     data_start = (pre + ALIGN - 1) // ALIGN * ALIGN
     tmp = path + ".tmp"
     with open(tmp, "wb") as f:
         f.write(MAGIC)
-        f.write(struct.pack("<II", VERSION, len(header)))
+        f.write(struct.pack("<III", VERSION, len(header), zlib.crc32(header) & 0xFFFFFFFF))
         f.write(header)
         f.write(b"\0" * (data_start - pre))
         for name, e in entries.items():
@@ -66,31 +72,93 @@ def write_shard_file(path: str, arrays: Dict[str, np.ndarray], meta: Dict) -> No
     os.replace(tmp, path)
 
 
+FINE_KS_LEN = 14  # len(DeviceIndex.FINE_KS)
+_EXPECT_DTYPE = {"term_ptr": "int64", "post_doc": "int32", "tile_skip": "int32", "idf": "float32", "term_bound": "float32",
+                 "fine_bound": "float32"}
+
+
+def _int_meta(path, meta, key, lo, hi):
+    v = meta.get(key)
+    if isinstance(v, bool) or not isinstance(v, int) or not (lo <= v <= hi):
+        raise ValueError(f"{path}: header field {key!r} = {v!r} is missing or out of range [{lo}, {hi}]")
+    return v
+
+
 def read_shard_file(path: str, verify: bool = True):
-    """-> (meta dict, {name: read-only np.memmap}).  Raises ValueError on a malformed / corrupted file."""
+    """-> (meta dict, {name: read-only np.memmap}).  Raises ValueError on a malformed, corrupted or self-inconsistent
+    file (see the module docstring for what is checked)."""
     size = os.path.getsize(path)
     with open(path, "rb") as f:
-        head = f.read(len(MAGIC) + 8)
-        if len(head) < len(MAGIC) + 8 or head[: len(MAGIC)] != MAGIC:
+        head = f.read(len(MAGIC) + 12)
+        if len(head) < len(MAGIC) + 12 or head[: len(MAGIC)] != MAGIC:
             raise ValueError(f"{path}: not a sparse-rx shard file")
-        version, hlen = struct.unpack("<II", head[len(MAGIC):])
+        version, hlen, hcrc = struct.unpack("<III", head[len(MAGIC):])
         if version != VERSION:
             raise ValueError(f"{path}: shard file version {version}, expected {VERSION}")
         if hlen > size:
             raise ValueError(f"{path}: truncated header")
-        hdr = json.loads(f.read(hlen).decode("utf-8"))
-    pre = len(MAGIC) + 8 + hlen
+        raw = f.read(hlen)
+        if len(raw) != hlen or (zlib.crc32(raw) & 0xFFFFFFFF) != hcrc:
+            raise ValueError(f"{path}: header checksum mismatch")
+        try:
+            hdr = json.loads(raw.decode("utf-8"))
+            meta, entries = hdr["meta"], hdr["arrays"]
+            assert isinstance(meta, dict) and isinstance(entries, dict)
+        except Exception as e:
+            raise ValueError(f"{path}: malformed header ({e})") from None
+    pre = len(MAGIC) + 12 + hlen
     data_start = (pre + ALIGN - 1) // ALIGN * ALIGN
-    out = {}
-    for name, e in hdr["arrays"].items():
-        if name not in _ARRAYS or e["dtype"] not in _DTYPES:
-            raise ValueError(f"{path}: unknown array {name!r} / dtype {e['dtype']!r}")
+    # ---- dims ----
+    n_docs = _int_meta(path, meta, "n_docs", 1, 0x7FFFFFFE)
+    vocab = _int_meta(path, meta, "vocab", 1, 1 << 40)
+    nnz = _int_meta(path, meta, "nnz", 0, 1 << 40)
+    tile_log2 = _int_meta(path, meta, "tile_log2", 6, 14)
+    pad = _int_meta(path, meta, "post_pad", 0, 1 << 20)
+    _int_meta(path, meta, "doc_base", 0, 1 << 62)
+    n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
+    want = {"term_ptr": vocab + 1, "post_doc": nnz + pad, "post_val": nnz + pad, "tile_skip": vocab * (n_tiles + 1),
+            "idf": vocab, "term_bound": vocab * 4, "fine_bound": vocab * FINE_KS_LEN}
+    for name in ("term_ptr", "post_doc", "post_val", "tile_skip", "idf"):
+        if name not in entries:
+            raise ValueError(f"{path}: array {name} is missing")
+    out, spans = {}, []
+    for name, e in entries.items():
+        if name not in _ARRAYS or not isinstance(e, dict) or e.get("dtype") not in _DTYPES:
+            raise ValueError(f"{path}: unknown array {name!r} / dtype {e.get('dtype') if isinstance(e, dict) else e!r}")
+        if name in _EXPECT_DTYPE and e["dtype"] != _EXPECT_DTYPE[name] or name == "post_val" and e["dtype"] not in ("float32", "float16"):
+            raise ValueError(f"{path}: array {name} has dtype {e['dtype']}")
         dt = np.dtype(_DTYPES[e["dtype"]])
-        start = data_start + int(e["offset"])
-        if int(e["count"]) < 0 or start + int(e["count"]) * dt.itemsize > size:
+        count, off = e.get("count"), e.get("offset")
+        if not isinstance(count, int) or not isinstance(off, int) or isinstance(count, bool) or isinstance(off, bool):
+            raise ValueError(f"{path}: array {name}: count / offset are not integers")
+        if count != want[name]:
+            raise ValueError(f"{path}: array {name} holds {count} elements, the header dims require {want[name]}")
+        if off < 0 or off % ALIGN:
+            raise ValueError(f"{path}: array {name}: offset {off} is negative or not {ALIGN}-aligned")
+        start = data_start + off
+        if start + count * dt.itemsize > size:
             raise ValueError(f"{path}: array {name} runs past the end of the file")
-        a = np.memmap(path, dtype=dt, mode="r", offset=start, shape=(int(e["count"]),)) if e["count"] else np.zeros(0, dt)
-        if verify and _crc(np.asarray(a)) != int(e["crc32"]):
-            raise ValueError(f"{path}: checksum mismatch in {name}")
-        out[name] = a
-    return hdr["meta"], out
+        spans.append((start, start + count * dt.itemsize, name))
+        out[name] = np.memmap(path, dtype=dt, mode="r", offset=start, shape=(count,)) if count else np.zeros(0, dt)
+    spans.sort()
+    for (a0, a1, an), (b0, b1, bn) in zip(spans, spans[1:]):
+        if b0 < a1:
+            raise ValueError(f"{path}: arrays {an} and {bn} overlap")
+    # ---- the offsets every kernel trusts ----
+    tp = np.asarray(out["term_ptr"])
+    if int(tp[0]) != 0 or int(tp[-1]) != nnz or np.any(np.diff(tp) < 0):
+        raise ValueError(f"{path}: term_ptr is not a non-decreasing offset table from 0 to nnz = {nnz}")
+    if verify:
+        for name, e in entries.items():
+            if _crc(np.asarray(out[name])) != int(e.get("crc32", -1)):
+                raise ValueError(f"{path}: checksum mismatch in {name}")
+        chunk = 1 << 24
+        pd = out["post_doc"]
+        for i in range(0, nnz, chunk):
+            blk = np.asarray(pd[i: min(i + chunk, nnz)])
+            if blk.size and (int(blk.min()) < 0 or int(blk.max()) >= n_docs):
+                raise ValueError(f"{path}: post_doc holds doc ids outside [0, {n_docs})")
+        ts = np.asarray(out["tile_skip"]).reshape(vocab, n_tiles + 1)
+        if np.any(ts[:, 0] != 0) or np.any(np.diff(ts, axis=1) < 0) or np.any(ts[:, -1].astype(np.int64) != np.diff(tp)):
+            raise ValueError(f"{path}: tile_skip rows are not non-decreasing counts from 0 to the term's posting count")
+    return meta, out

@@ -115,18 +115,31 @@ def test_npz_cache_schema_roundtrip(golden_dir, tmp_path):
     assert np.array_equal(h2.idf.view(np.uint32), h.idf.view(np.uint32)) and h2.avgdl == np.float32(h.avgdl)
 
 
+def _consistent_shard(rng, V=37, n_docs=5000, tile_log2=11, pad=16, val_dtype=np.float16):
+    """Arrays of one small shard that satisfy every invariant read_shard_file checks."""
+    n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
+    df = rng.integers(0, 60, V)
+    term_ptr = np.zeros(V + 1, np.int64)
+    term_ptr[1:] = np.cumsum(df)
+    nnz = int(term_ptr[-1])
+    post_doc = np.zeros(nnz + pad, np.int32)
+    tile_skip = np.zeros((V, n_tiles + 1), np.int32)
+    for t in range(V):
+        docs = np.sort(rng.choice(n_docs, df[t], replace=False)).astype(np.int32)
+        post_doc[term_ptr[t]:term_ptr[t + 1]] = docs
+        tile_skip[t] = np.searchsorted(docs, np.arange(n_tiles + 1) << tile_log2)
+    arrays = {"term_ptr": term_ptr, "post_doc": post_doc, "post_val": rng.random(nnz + pad).astype(val_dtype),
+              "tile_skip": tile_skip.reshape(-1), "idf": rng.random(V).astype(np.float32),
+              "term_bound": rng.random(V * 4).astype(np.float32)}
+    meta = {"n_docs": n_docs, "vocab": V, "nnz": nnz, "doc_base": 123456789012, "tile_log2": tile_log2, "post_pad": pad}
+    return arrays, meta
+
+
 def test_shard_file_roundtrip_and_corruption(tmp_path):
     """Native shard file: header + aligned raw arrays; roundtrip is bit-exact, corruption is detected."""
     from sparse_rx import shardfile
     rng = np.random.default_rng(3)
-    V, nnz, n_tiles = 37, 1000, 3
-    arrays = {"term_ptr": np.sort(rng.integers(0, nnz, V + 1)).astype(np.int64),
-              "post_doc": rng.integers(0, 5000, nnz + 16).astype(np.int32),
-              "post_val": rng.random(nnz + 16).astype(np.float16),
-              "tile_skip": rng.integers(0, 99, V * (n_tiles + 1)).astype(np.int32),
-              "idf": rng.random(V).astype(np.float32),
-              "term_bound": rng.random(V * 4).astype(np.float32)}
-    meta = {"n_docs": 5000, "vocab": V, "nnz": nnz, "doc_base": 123456789012, "tile_log2": 11, "post_pad": 16}
+    arrays, meta = _consistent_shard(rng)
     p = str(tmp_path / "shard0.srx")
     shardfile.write_shard_file(p, arrays, meta)
     m2, a2 = shardfile.read_shard_file(p)
@@ -150,3 +163,120 @@ def test_shard_file_roundtrip_and_corruption(tmp_path):
     open(p, "wb").write(b"NOTSHARD" + bytes(100))
     with pytest.raises(ValueError, match="not a sparse-rx shard file"):
         shardfile.read_shard_file(p)
+
+
+def _rewrite_header(path, edit):
+    """Apply `edit(header_dict)` to a shard file's JSON header and write it back WITH a matching header CRC (a header
+    that is wrong but internally well-formed: what the structural validation has to catch)."""
+    import struct
+    import zlib
+    from sparse_rx import shardfile
+    raw = open(path, "rb").read()
+    n0 = len(shardfile.MAGIC)
+    version, hlen, _ = struct.unpack("<III", raw[n0:n0 + 12])
+    hdr = json.loads(raw[n0 + 12:n0 + 12 + hlen].decode())
+    edit(hdr)
+    new = json.dumps(hdr, sort_keys=True).encode()
+    data_start_old = (n0 + 12 + hlen + 4095) // 4096 * 4096
+    data_start_new = (n0 + 12 + len(new) + 4095) // 4096 * 4096
+    assert data_start_new == data_start_old
+    out = raw[:n0] + struct.pack("<III", version, len(new), zlib.crc32(new) & 0xFFFFFFFF) + new
+    out += b"\0" * (data_start_new - len(out)) + raw[data_start_old:]
+    open(path, "wb").write(out)
+
+
+def test_shard_file_header_is_validated(tmp_path):
+    """A damaged or mismatched header must raise ValueError before anything is uploaded: the kernels index the arrays
+    with the header's dims and get raw pointers without sizes (round-1 advisor finding)."""
+    from sparse_rx import shardfile
+    rng = np.random.default_rng(4)
+    arrays, meta = _consistent_shard(rng, val_dtype=np.float32)
+    good = str(tmp_path / "good.srx")
+    shardfile.write_shard_file(good, arrays, meta)
+    shardfile.read_shard_file(good)
+    p = str(tmp_path / "bad.srx")
+
+    def case(edit, match, verify=True):
+        import shutil
+        shutil.copy(good, p)
+        _rewrite_header(p, edit)
+        with pytest.raises(ValueError, match=match):
+            shardfile.read_shard_file(p, verify=verify)
+
+    # a single flipped header byte (no CRC fix-up) is caught by the header checksum
+    raw = bytearray(open(good, "rb").read())
+    raw[30] ^= 0x01
+    open(p, "wb").write(raw)
+    with pytest.raises(ValueError, match="header checksum"):
+        shardfile.read_shard_file(p)
+    # dims that disagree with the arrays (each would be an out-of-bounds device read)
+    case(lambda h: h["meta"].__setitem__("vocab", meta["vocab"] + 1), "header dims require", verify=False)
+    case(lambda h: h["meta"].__setitem__("n_docs", meta["n_docs"] * 4), "header dims require", verify=False)   # more tiles -> longer skip rows
+    case(lambda h: h["meta"].__setitem__("nnz", meta["nnz"] + 8), "header dims require", verify=False)
+    case(lambda h: h["meta"].__setitem__("tile_log2", 9), "header dims require", verify=False)
+    case(lambda h: h["meta"].__setitem__("tile_log2", 40), "out of range", verify=False)
+    case(lambda h: h["meta"].pop("n_docs"), "missing or out of range", verify=False)
+    case(lambda h: h["meta"].__setitem__("nnz", -1), "out of range", verify=False)
+    # offsets: negative, unaligned, overlapping, past the end
+    case(lambda h: h["arrays"]["idf"].__setitem__("offset", -4096), "negative or not", verify=False)
+    case(lambda h: h["arrays"]["idf"].__setitem__("offset", 100), "negative or not", verify=False)
+    case(lambda h: h["arrays"]["idf"].__setitem__("offset", h["arrays"]["term_ptr"]["offset"]), "overlap", verify=False)
+    case(lambda h: h["arrays"]["idf"].__setitem__("offset", 1 << 40), "past the end", verify=False)
+    case(lambda h: h["arrays"]["post_doc"].__setitem__("dtype", "float32"), "dtype", verify=False)
+    case(lambda h: h["arrays"].pop("tile_skip"), "missing", verify=False)
+    # contents the kernels trust: term_ptr, doc ids, skip rows (the last two need the data pass of verify=True)
+    def swap(a, b):
+        def f(h):
+            h["arrays"][a]["offset"], h["arrays"][b]["offset"] = h["arrays"][b]["offset"], h["arrays"][a]["offset"]
+        return f
+    bad_tp = dict(arrays)
+    bad_tp["term_ptr"] = arrays["term_ptr"].copy()
+    bad_tp["term_ptr"][5] = bad_tp["term_ptr"][6] + 3  # decreasing
+    shardfile.write_shard_file(p, bad_tp, meta)
+    with pytest.raises(ValueError, match="term_ptr"):
+        shardfile.read_shard_file(p, verify=False)
+    bad_doc = dict(arrays)
+    bad_doc["post_doc"] = arrays["post_doc"].copy()
+    bad_doc["post_doc"][3] = meta["n_docs"] + 7
+    shardfile.write_shard_file(p, bad_doc, meta)
+    with pytest.raises(ValueError, match="post_doc"):
+        shardfile.read_shard_file(p)
+    bad_ts = dict(arrays)
+    bad_ts["tile_skip"] = arrays["tile_skip"].copy()
+    bad_ts["tile_skip"][-1] += 5  # the last term's row no longer ends at its posting count
+    shardfile.write_shard_file(p, bad_ts, meta)
+    with pytest.raises(ValueError, match="tile_skip"):
+        shardfile.read_shard_file(p)
+
+
+def test_query_batch_validation():
+    """The host-array entry point checks srx_search's preconditions before launching (round-1 advisor finding): an
+    out-of-range term id would be an out-of-bounds device read, a repeated term breaks one-posting-per-(doc, term)."""
+    from sparse_rx.index import validate_query_batch
+    ok = (np.array([0, 2, 2, 5], np.int32), np.array([3, 1, 9, 0, 4], np.int32), np.ones(5, np.float32))
+    validate_query_batch(*ok, vocab=10)  # terms need not be ascending (token order is legal)
+    validate_query_batch(np.array([0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), vocab=10)
+    for q_ptr, q_term, msg in ((np.array([1, 2, 5]), ok[1], "start at 0"), (np.array([0, 3, 2, 5]), ok[1], "non-decreasing"),
+                               (ok[0], np.array([3, 1, 10, 0, 4]), "out of range"), (ok[0], np.array([3, 1, -1, 0, 4]), "out of range"),
+                               (ok[0], np.array([3, 3, 9, 0, 4]), "same term twice"), (ok[0], np.array([3, 1, 9, 0, 9]), "same term twice"),
+                               (np.array([0, 2, 2, 7]), ok[1], "shorter")):
+        with pytest.raises(ValueError, match=msg):
+            validate_query_batch(q_ptr.astype(np.int32), q_term.astype(np.int32), ok[2], vocab=10)
+    validate_query_batch(ok[0], np.array([3, 1, 3, 0, 4], np.int32), ok[2], vocab=10)  # the same term in DIFFERENT queries is fine
+
+
+def test_encode_queries_token_order(golden_dir):
+    """order="token": first-occurrence order of the in-vocabulary terms -- the pipeline twin's ``relevant_terms``
+    (evaluate_rag_pipeline.py:360-370), pinned by the token-ordered lists the reference run recorded."""
+    p = np.load(os.path.join(golden_dir, "pipeline_small.npz"))
+    j = json.load(open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8"))
+    h = sparse_rx.build_host_index(j["corpus"])
+    qids = [str(q) for q in p["bm25_qids"]]
+    q_ptr, q_term, q_w = sparse_rx.encode_queries([j["queries"][q] for q in qids], h.vocabulary, order="token")
+    assert np.array_equal(q_ptr, p["bm25_q_ptr"]) and np.array_equal(q_term, p["bm25_q_term"]) and np.array_equal(q_w, p["bm25_q_weight"])
+    a = sparse_rx.encode_queries(["w9 w8 w7 w9"], h.vocabulary, order="token")
+    b = sparse_rx.encode_queries(["w9 w8 w7 w9"], h.vocabulary)
+    assert list(a[1]) == [h.vocabulary[w] for w in ("w9", "w8", "w7")] and list(b[1]) == sorted(a[1])
+    assert sorted(zip(a[1], a[2])) == list(zip(b[1], b[2]))
+    with pytest.raises(ValueError):
+        sparse_rx.encode_queries(["w1"], h.vocabulary, order="nope")

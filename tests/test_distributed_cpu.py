@@ -158,34 +158,37 @@ def test_combined_term_bounds_are_lower_bounds():
     assert better >= 2 * (V - 5)  # the shared bound is the stronger one for K = 10, 100, 1000 on similar shards
 
 
-def _bounds_worker(rank, world, port, ret):
+def _bounds_worker(rank, world, port, ret, no_table_rank=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sparse_rx
     from sparse_rx.index import DeviceIndex, combine_term_bounds
 
-    class FakeIndex:  # the collective wiring only needs these two members
+    class FakeIndex:  # the collective wiring only needs these members
         def __init__(self, t):
-            self.fine_bound, self.table = t, None
+            self.fine_bound, self.table, self.vocab, self.device = t, None, 50, torch.device("cpu")
 
         def set_term_bound(self, table):
             self.table = table
 
     tabs = [torch.from_numpy(np.random.default_rng(100 + r).random((50, len(DeviceIndex.FINE_KS))).astype(np.float32)) for r in range(world)]
-    ix = FakeIndex(tabs[rank])
-    sparse_rx.global_term_bounds(ix)
+    if no_table_rank is not None:
+        tabs[no_table_rank] = torch.zeros_like(tabs[no_table_rank])  # what a shard without a table contributes
+    ix = FakeIndex(None if rank == no_table_rank else tabs[rank])
+    sparse_rx.global_term_bounds(ix)  # must not hang when only SOME ranks lack a table (round-1 advisor finding)
     ret[rank] = bool(ix.table is not None and torch.equal(ix.table, combine_term_bounds(tabs, world)))
     dist.destroy_process_group()
 
 
-def test_global_term_bounds_collective():
+@pytest.mark.parametrize("no_table_rank", [None, 1])
+def test_global_term_bounds_collective(no_table_rank):
     world = 3
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
         ret = m.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_bounds_worker, args=(r, world, port, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_bounds_worker, args=(r, world, port, ret, no_table_rank)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:

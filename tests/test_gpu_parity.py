@@ -209,6 +209,17 @@ def test_edge_cases(rx):
         ix.search(*q, 0)
     with pytest.raises(ValueError):
         ix.search(*q, 1025)
+    # host batches are validated before any launch: out-of-range / repeated terms never reach the kernels
+    with pytest.raises(ValueError, match="out of range"):
+        ix.search(np.array([0, 2], np.int32), np.array([1, 700], np.int32), np.ones(2, np.float32), 10)
+    with pytest.raises(ValueError, match="same term twice"):
+        ix.search(np.array([0, 2], np.int32), np.array([5, 5], np.int32), np.ones(2, np.float32), 10)
+    # term order inside a query = accumulation order: descending ids == the given-order oracle
+    rq = (q_ptr, np.concatenate([x[::-1] for x in qs]), q_w)
+    got = ix.search(*rq, 100)
+    exp = oracle.search_batch(c.indptr, c.indices, c.data, c.doc_lengths, idf, *rq, 100, 1.2, 0.75, avgdl,
+                              mode=oracle.MODE_BM25_F32_GIVEN_ORDER)
+    _assert_exact(got, exp, "edge reversed-term order")
     ix.close()
     # n_docs not a multiple of the tile, single doc, all-identical docs (one giant tie group)
     rows = 1000
@@ -364,21 +375,104 @@ def test_registry_twin_golden(rx, golden_dir, tmp_path):
         rx.RetrieverRegistry.create({"type": "dpr", "params": {"quantization_method": "asymmetric"}})
     with pytest.raises(ValueError):
         rx.RetrieverRegistry.create({"type": "nope"})
-    # pipeline twin: bm25 == the service; .npz cache written then reused
-    pr = rx.OptimizedRetriever({"type": "bm25", "params": {"k1": 1.2, "b": 0.75}}, {"memory_gb": 8, "cores": 4},
-                               tile_log2=6, cache_dir=str(tmp_path / "cache"))
-    pr.build_index_from_corpus(j["corpus"])
-    first = pr.search(j["queries"], top_k=10)
-    assert len(list((tmp_path / "cache").glob("bm25_index_*.npz"))) == 1
-    pr2 = rx.OptimizedRetriever({"type": "bm25"}, {"memory_gb": 8, "cores": 4}, tile_log2=6, cache_dir=str(tmp_path / "cache"))
-    pr2.build_index_from_corpus(j["corpus"])  # loads the cache
-    assert pr2.search(j["queries"], top_k=10) == first
-    exp = j["results"]["10"]
+
+
+def _assert_dict_results(got, exp, row, k, label):
+    assert list(got.keys()) == list(exp.keys()), label
     for qid in exp:
-        assert list(first[qid].keys()) == list(first[qid].keys())
-        assert np.array_equal(np.array(list(first[qid].values()), np.float32), np.array(list(exp[qid].values()), np.float32)), qid
-    pr.close()
-    pr2.close()
+        g, e = got[qid], exp[qid]
+        assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                            np.array(list(e.values()), np.float32), k=k, label=f"{label} {qid}")
+
+
+@pytest.mark.parametrize("name,cfg", [("bm25", {"type": "bm25", "params": {"k1": 1.2, "b": 0.75}}),
+                                      ("bm25_custom", {"type": "bm25_custom", "params": {"k1": 1.6, "b": 0.8}}),
+                                      ("splade", {"type": "splade"}), ("dpr", {"type": "dpr"})])
+def test_pipeline_twin_golden(rx, golden_dir, tmp_path, name, cfg):
+    """registry.OptimizedRetriever against the ``search`` results the REFERENCE's OptimizedRetriever produced
+    (evaluate_rag_pipeline.py:162-479; tests/golden/pipeline_small.json): bm25 types score with BM25, every other type
+    with the tf-idf dot product and idf = log(N/(df+1)).  Scores must be bit-equal -- the twin's NumPy fallback adds a
+    doc's contributions in query-token order, which the engine reproduces (accumulation="token") -- and ranks equal
+    modulo the reference's unspecified order inside exact ties.  Three ways to the index: built from the text, loaded
+    from the cache this build wrote, loaded from the .npz the reference itself wrote."""
+    import shutil
+    with open(os.path.join(golden_dir, "pipeline_small.json"), encoding="utf-8") as f:
+        pj = json.load(f)
+    with open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8") as f:
+        j = json.load(f)
+    hw = {"memory_gb": 8, "cores": 4}
+    cache = tmp_path / "cache"
+    r = rx.OptimizedRetriever(cfg, hw, tile_log2=6, cache_dir=str(cache))
+    assert (r.k1, r.b) == (pj[name]["k1"], pj[name]["b"])
+    assert r.mode == ("bm25" if name.startswith("bm25") else "dot")
+    r.build_index_from_corpus(j["corpus"])
+    row = {d: i for i, d in enumerate(r.doc_ids)}
+    written = list(cache.glob(f"{cfg['type']}_index_*.npz"))
+    assert [w.name for w in written] == [f"{cfg['type']}_index_4619a0fc.npz"]  # the reference's file name for this corpus (:189-192)
+    fresh = {}
+    for k in ("5", "50"):
+        fresh[k] = r.search(j["queries"], top_k=int(k))
+        _assert_dict_results(fresh[k], pj[name]["results"][k], row, int(k), f"{name} fresh k={k}")
+        assert r.search(j["queries"], top_k=int(k)) == fresh[k]  # query-cache hits
+    r.close()
+    r2 = rx.OptimizedRetriever(cfg, hw, tile_log2=6, cache_dir=str(cache))
+    r2.build_index_from_corpus(j["corpus"])  # loads the cache written above
+    for k in ("5", "50"):
+        assert r2.search(j["queries"], top_k=int(k)) == fresh[k]
+    r2.close()
+    ref_file = os.path.join(golden_dir, "ref_cache", f"{cfg['type']}_index_4619a0fc.npz")
+    if os.path.exists(ref_file):  # bm25 and splade: the cache file written by the reference
+        cache3 = tmp_path / "cache_ref"
+        cache3.mkdir()
+        shutil.copy(ref_file, cache3)
+        r3 = rx.OptimizedRetriever(cfg, hw, tile_log2=6, cache_dir=str(cache3))
+        r3.build_index_from_corpus(j["corpus"])
+        assert sorted(x.name for x in cache3.iterdir()) == [os.path.basename(ref_file)]  # used, not rebuilt
+        for k in ("5", "50"):
+            got = r3.search(j["queries"], top_k=int(k))
+            assert got == fresh[k]
+            _assert_dict_results(got, pj[name]["results"][k], row, int(k), f"{name} ref-cache k={k}")
+        r3.close()
+    # accumulation="term" (the Numba kernels' CSR-row order) == the given-order oracle fed ascending terms
+    r4 = rx.OptimizedRetriever(cfg, {"memory_gb": 2, "cores": 4}, tile_log2=6, cache_dir=str(cache), accumulation="term")
+    assert r4.query_cache is None  # memory_gb <= 4: no query cache, no index cache (:170-173)
+    r4.build_index_from_corpus(j["corpus"])
+    h = r4.host
+    qids = list(j["queries"])
+    q = rx.encode_queries([j["queries"][x] for x in qids], h.vocabulary)
+    mode = oracle.MODE_BM25_F32 if name.startswith("bm25") else oracle.MODE_TFIDF_F32
+    ed, es, ec = oracle.search_batch(h.indptr, h.indices, h.data, h.doc_lengths, h.idf, *q, 50, r4.k1, r4.b, h.avgdl, mode=mode)
+    got = r4.search(j["queries"], top_k=50)
+    for i, qid in enumerate(qids):
+        assert [row[d] for d in got[qid]] == ed[i, :ec[i]].tolist(), qid
+        assert np.array_equal(np.array(list(got[qid].values()), np.float32).view(np.uint32), es[i, :ec[i]].view(np.uint32)), qid
+    r4.close()
+
+
+def test_c1_fiqa_shaped_end_to_end(rx):
+    """BASELINE config C1: FiQA-shaped synthetic text (57 638 docs, ~80 k Zipf words, ~130 tokens / doc, 100 queries of
+    ~10 words; real FiQA is not available offline) through RetrievalService.build_bm25_index / search_bm25(top_k=10),
+    compared bit for bit with the oracle run on the host CSR the service built (same canonical tie order)."""
+    from sparse_rx import synth
+    corpus, queries = synth.fiqa_shaped_text()
+    svc = rx.RetrievalService(device="cuda:0")
+    svc.build_bm25_index(corpus)
+    h = svc.host
+    assert h.n_docs == 57_638
+    got = svc.search_bm25(queries, top_k=10)
+    assert list(got.keys()) == list(queries.keys())
+    qids = list(queries)
+    q = rx.encode_queries([queries[x] for x in qids], h.vocabulary)
+    ed, es, ec = oracle.search_batch(h.indptr, h.indices, h.data, h.doc_lengths, h.idf, *q, 10, 1.2, 0.75, h.avgdl)
+    row = {d: i for i, d in enumerate(h.doc_ids)}
+    for i, qid in enumerate(qids):
+        g = got[qid]
+        assert [row[d] for d in g] == ed[i, :ec[i]].tolist(), qid
+        assert np.array_equal(np.array(list(g.values()), np.float32).view(np.uint32), es[i, :ec[i]].view(np.uint32)), qid
+    # k = 50 (the reference's FiQA experiment, rag_system/configs/paper_results.yaml:11) and the raw arrays
+    gd, gs, gc = svc.dev.search(*q, 50)
+    _assert_exact((gd, gs, gc), oracle.search_batch(h.indptr, h.indices, h.data, h.doc_lengths, h.idf, *q, 50, 1.2, 0.75, h.avgdl), "c1 k=50")
+    svc.close()
 
 
 def test_fuzz_shapes_vs_oracle(rx):
@@ -418,7 +512,6 @@ def test_shard_file_save_load(rx, tmp_path):
     for mode, vd in (("bm25", "f32"), ("dot", "f16")):
         a = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, doc_lengths=c.doc_lengths, avgdl=avgdl, mode=mode,
                                     val_dtype=vd, tile_log2=11, doc_base=777)
-        exp = a.search(*q, 50)
         p = str(tmp_path / f"s_{mode}.srx")
         a.save(p)
         a.close()
@@ -426,8 +519,26 @@ def test_shard_file_save_load(rx, tmp_path):
         assert (b.n_docs, b.vocab, b.doc_base, b.tile_log2, b.nnz) == (c.n_docs, c.vocab, 777, 11, len(c.indices))
         got = b.search(*q, 50)
         b.close()
-        for x, y in zip(got, exp):
-            assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+        # the loaded index against the ORACLE (not against the index it was saved from); stored values of the Zipf
+        # corpus (term counts) are exact in fp16, so the f16 shard has the f32 oracle's scores
+        ed, es, ec = _oracle_batch(c, idf, avgdl, q, 50, mode=oracle.MODE_BM25_F32 if mode == "bm25" else oracle.MODE_TFIDF_F32)
+        ed = np.where(ed >= 0, ed + 777, -1).astype(np.int32)  # doc_base travels in the file
+        _assert_exact(got, (ed, es, ec), f"shard file {mode}/{vd}")
+    # a header that disagrees with its arrays never reaches the GPU
+    import json as _json
+    import struct
+    import zlib
+    raw = open(p, "rb").read()
+    hlen = struct.unpack("<I", raw[12:16])[0]
+    hdr = _json.loads(raw[20:20 + hlen])
+    hdr["meta"]["vocab"] += 3
+    new = _json.dumps(hdr, sort_keys=True).encode()
+    assert (20 + len(new) + 4095) // 4096 == (20 + hlen + 4095) // 4096
+    ds = (20 + hlen + 4095) // 4096 * 4096
+    bad = raw[:8] + struct.pack("<III", 2, len(new), zlib.crc32(new) & 0xFFFFFFFF) + new
+    open(p, "wb").write(bad + b"\0" * (ds - len(bad)) + raw[ds:])
+    with pytest.raises(ValueError, match="header dims require"):
+        rx.DeviceIndex.load(p)
 
 
 def test_corpus_wide_bounds_keep_sharded_search_exact(rx):
@@ -470,3 +581,77 @@ def test_corpus_wide_bounds_keep_sharded_search_exact(rx):
             assert n_global < n_local  # shards return only what can still reach the corpus-wide top k
         for ix in ixs:
             ix.close()
+
+
+def test_host_batch_pipeline(rx):
+    """HostBatchPipeline (pinned, double-buffered H2D / D2H on copy streams): several different batches in flight,
+    every result equal to the oracle's; misuse (unread slot, oversize batch, bad term id) raises."""
+    from sparse_rx import synth
+    c = synth.uniform_corpus_np(80_000, 6_000, 30, seed=31)
+    _, idf, avgdl = synth.corpus_stats(c)
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=11)
+    k = 100
+    batches = [synth.queries_np(n, c.vocab, t, seed=40 + i) for i, (n, t) in enumerate([(200, 8), (1, 3), (137, 12), (200, 8), (64, 1), (199, 5)])]
+    pipe = rx.HostBatchPipeline(ix, 200, 200 * 12, k, depth=2)
+    tickets, got = [], []
+    for b in batches:
+        tickets.append(pipe.submit(*b))
+        if len(tickets) == 2:
+            got.append(tuple(x.copy() for x in pipe.result(tickets.pop(0))))
+    while tickets:
+        got.append(tuple(x.copy() for x in pipe.result(tickets.pop(0))))
+    for i, (b, g) in enumerate(zip(batches, got)):
+        _assert_exact(g, _oracle_batch(c, idf, avgdl, b, k), f"pipeline batch {i}")
+    _assert_exact(pipe.search(*batches[2]), _oracle_batch(c, idf, avgdl, batches[2], k), "pipeline sync search")
+    t0 = pipe.submit(*batches[0])
+    pipe.submit(*batches[1])
+    with pytest.raises(RuntimeError, match="unread"):
+        pipe.submit(*batches[2])
+    pipe.result(t0)
+    with pytest.raises(RuntimeError):
+        pipe.result(t0)
+    with pytest.raises(ValueError, match="larger"):
+        pipe.submit(*synth.queries_np(201, c.vocab, 4, seed=1))
+    with pytest.raises(ValueError, match="out of range"):
+        pipe.submit(np.array([0, 1], np.int32), np.array([6000], np.int32), np.ones(1, np.float32))
+    pipe.close()
+    ix.close()
+
+
+def test_sharded_searcher_overlap_on_one_gpu(rx):
+    """The N > 1 code path on ONE GPU (RCCL process group of one rank, force_exchange): packed rows written into the
+    send buffer, all-to-all / all-gather, packed merge -- with the exchange of batch i overlapping the scoring of batch
+    i+1 on a second stream (double-buffered slots, event guards).  Several different batches back to back without a
+    synchronisation in between; after wait() every batch equals the oracle."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from sparse_rx import synth
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = synth.uniform_corpus_np(100_000, 5_000, 30, seed=51)
+        _, idf, avgdl = synth.corpus_stats(c)
+        ix = _dev_index(rx, c, idf, avgdl, tile_log2=11, doc_base=1000)
+        k = 50
+        batches = [synth.queries_np(300, c.vocab, 6, seed=60 + i) for i in range(5)]
+        dev_batches = [[torch.as_tensor(x, device="cuda:0") for x in b] for b in batches]
+        exps = []
+        for b in batches:
+            ed, es, ec = _oracle_batch(c, idf, avgdl, b, k)
+            exps.append((np.where(ed >= 0, ed + 1000, -1).astype(np.int32), es, ec))
+        for mode in ("a2a", "allgather"):
+            for overlap in (True, False):
+                s = rx.ShardedSearcher.for_device_index(ix)
+                s.force_exchange, s.overlap, s.mode = True, overlap, mode
+                outs = [s.search(*qb, k) for qb in dev_batches]  # no synchronisation between the batches
+                s.wait()
+                torch.cuda.synchronize()
+                for i, (o, e) in enumerate(zip(outs, exps)):
+                    _assert_exact(tuple(x.contiguous().cpu().numpy() for x in o), e, f"{mode} overlap={overlap} batch {i}")
+        ix.close()
+    finally:
+        dist.destroy_process_group()

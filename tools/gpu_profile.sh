@@ -4,6 +4,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 tag=$1; shift
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
+echo "$@" > $out/args.txt
 export TMPDIR=/tmp
 ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $@"
 # the kernel-trace pass runs the bench's own default protocol (3 warm-up + 20 timed steps), so that its per-launch
