@@ -15,7 +15,7 @@ full build_bm25_index path, k = 10), "c4" / "c5" configs[3] / configs[4].
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Fields beyond the contract:
   value / ms_per_step          device-resident: the query batch is in HBM when the timed region starts, results stay there
-  config.pcie_inclusive_qps    the same steps fed from HOST batches (pinned, double-buffered H2D of the query CSR and
+  config.pcie_inclusive_qps    the same steps fed from HOST batches (pinned, multi-buffered H2D of the query CSR and
                                D2H of the nq x k result rows on copy streams, overlapped with the search of the next
                                batch) -- SURVEY.md 8(d)'s "batch wall time incl. H2D and D2H"
   roofline.achieved / frac     algorithmic bytes of one step / the scoring kernels' time per step (hipEvents recorded on
@@ -43,10 +43,27 @@ if ROOT not in sys.path:
 
 
 def _cpu_share() -> int:
+    """Cores this process may actually use: the scheduler affinity, cut down to the cgroup CPU quota when there is one
+    (a GPU box hands a 1-GPU job a share of the host's cores; more threads than that only oversubscribe it)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 # CPU-baseline threads: every core this process may run on (BASELINE.md 3: OMP_NUM_THREADS = nproc); with N ranks on one
@@ -145,6 +162,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="dev: on one GPU, use the score bounds a shard would get among this many identical shards")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
+    ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
     args = ap.parse_args()
@@ -323,16 +341,16 @@ def main():
     # ---- PCIe-inclusive: the same steps fed from host batches through the pinned double-buffered pipeline ----------
     pcie_qps = pcie_ms = None
     if dist is None:
-        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=2)
+        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=args.pipe_depth)
         n_p = max(6, min(args.steps, 40))
         tickets = []
-        for i in range(2):  # warm-up (pinned buffers touched, streams created)
+        for i in range(args.pipe_depth):  # warm-up (pinned buffers touched, streams created)
             pipe.result(pipe.submit(q_ptr, q_term, q_w))
         torch.cuda.synchronize(dev)
         t = time.perf_counter()
         for i in range(n_p):
             tickets.append(pipe.submit(q_ptr, q_term, q_w))
-            if len(tickets) == 2:
+            if len(tickets) == args.pipe_depth:
                 pd_, ps_, pc_ = pipe.result(tickets.pop(0))  # host arrays (views of the pinned result slot)
         while tickets:
             pd_, ps_, pc_ = pipe.result(tickets.pop(0))
@@ -341,13 +359,13 @@ def main():
         rd, rs, rc_ = (x.cpu().numpy() for x in res)
         if not args.debug and not (np.array_equal(pd_, rd) and np.array_equal(ps_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(pc_, rc_)):
             raise SystemExit("PARITY FAILURE: the host-batch pipeline returned rows that differ from the device-resident search")
-        log(f"[bench] PCIe-inclusive (host query batch in, host results out, pinned + double-buffered): {pcie_qps:,.0f} queries/s "
+        log(f"[bench] PCIe-inclusive (host query batch in, host results out, pinned, {args.pipe_depth} slots): {pcie_qps:,.0f} queries/s "
             f"({pcie_ms:.3f} ms/step vs {1e3 * elapsed / args.steps:.3f} device-resident)")
         ix.profile_read()
         pipe.close()
 
     # ---- roofline of the dominant kernel (this rank's scoring kernels) --------------------------------------------
-    post_bytes = 8 if ix.post_val.dtype == torch.float32 else 6
+    post_bytes = 4 + ix.value_bytes  # 4-byte doc id + the stored value
     alg_bytes = int(df_local[qt.long()].sum().item()) * post_bytes + nq * k * 8  # sum df_t*(4+4) + k*8, this shard
     # Dominant kernel = the tier-1 wave kernel; the tier-2 block kernel's time is kept in the denominator so that no
     # posting byte is counted without its time.  Per STEP: the per-call averages times the calls one step makes.

@@ -11,8 +11,8 @@
  *                         (twins: rag_system/core/retriever_registry.py:287-297,304;
  *                                 rag_system/pipeline/evaluate_rag_pipeline.py:380-399,406 incl. simd_tfidf_score)
  *   srx_build_impacts     evaluates the per-posting BM25 term  retrieval.py:58,70-71  once at index build
- *   srx_build_tile_skip   device index construction (no reference counterpart: the reference scans the
- *                         whole doc-major CSR per query, retrieval.py:55-72)
+ *   srx_build_tile_skip,  device index construction (no reference counterpart: the reference scans the
+ *   srx_build_blocks      whole doc-major CSR per query, retrieval.py:55-72)
  *   srx_merge_topk        the (score desc, doc asc) merge of per-shard / per-split top-k lists
  *                         (multi-GPU: after the RCCL all-gather; no reference counterpart)
  *
@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 100 /* 0.1.0 */
+#define SRX_VERSION 200 /* 0.2.0: blocked posting layout */
 
 typedef enum {
     SRX_OK = 0,
@@ -53,19 +53,30 @@ typedef enum {
 /* Limits of this build (srx_limits() returns them at run time). */
 #define SRX_MAX_K 1024         /* largest top-k */
 #define SRX_MAX_TILE_LOG2 14   /* skip-table granularity G = 2^tile_log2 docs, G <= 16384 */
-#define SRX_POST_PAD 16         /* post_doc / post_val must be readable up to this many elements past nnz
-                                  (vector loads of 4 postings may run past a list's end; the values are ignored) */
+#define SRX_BLOCK_PAD 64        /* sentinel blocks behind the last run: post must hold n_blocks + SRX_BLOCK_PAD blocks */
 
 /*
- * Device-resident inverted index of one doc-range shard (term-major CSC + tile skip table).
- *   term_ptr[t] .. term_ptr[t+1]   postings of term t, ascending shard-local doc id
- *   post_doc[p]                    shard-local doc row of posting p
- *   post_val[p]                    BM25: impact = (tf*(k1+1)) / (tf + k1*(1-b+b*len/avgdl)) precomputed in fp32
+ * Device-resident inverted index of one doc-range shard: term-major postings in BLOCKS + a tile skip table.
+ *
+ * The postings of a term (ascending shard-local doc id) are cut into one run per UNIT of unit_tiles * G consecutive
+ * docs (unit_tiles * G <= 65536 for the tier-1 kernel; srx_auto_unit_tiles picks it).  Every run is padded to a
+ * multiple of 4 postings with sentinels (doc -1 - 32 * (term % 64), value 0; trailing sentinel block j holds docs
+ * -1 - 32 j) and stored as blocks of 4 postings, docs and values side by side:
+ *     SRX_VAL_F32: [d0 d1 d2 d3 | v0 v1 v2 v3]   8 x 32-bit words
+ *     SRX_VAL_F16: [d0 d1 d2 d3 | h0 h1 h2 h3]   6 words (4 docs, 4 halves)
+ * Negative doc ids mark sentinels.  A posting whose stored value is exactly 0 is ignored by every kernel (it would add +-0 and can never be a result:
+ * only scores > 0 are returned, retrieval.py:295).  "Padded position" p = block p >> 2, slot p & 3, counted over the
+ * whole array.  srx_build_blocks produces all of this from plain term-major arrays.
+ *
+ *   term_ptr[t]                    padded position of term t's first posting (a multiple of 4); term_ptr[vocab] = end
+ *   post                           the blocks; n_blocks of them, followed by SRX_BLOCK_PAD all-sentinel blocks
+ *   stored value                   BM25: impact = (tf*(k1+1)) / (tf + k1*(1-b+b*len/avgdl)) precomputed in fp32
  *                                  (retrieval.py:58,70-71); dot mode: the stored weight (tf)
- *   tile_skip[t*(n_tiles+1) + j]   number of postings of term t with doc < j*G  (so the run of term t
- *                                  inside docs [a*G, b*G) is [term_ptr[t]+skip[a], term_ptr[t]+skip[b]) )
+ *   tile_skip[t*(n_tiles+1) + j]   padded postings of term t with doc < j*G, relative to term_ptr[t] (so the run of
+ *                                  term t inside docs [a*G, b*G) is [term_ptr[t]+skip[a], term_ptr[t]+skip[b]) );
+ *                                  a multiple of 4 wherever j is a multiple of unit_tiles, and for j = n_tiles
  *   idf[t]                         per-term weight (retrieval.py:189; evaluate_rag_pipeline.py:273-278)
- * Per-posting contribution at query time: (post_val * idf[t]) * q_weight, fp32, summed per doc in the order the
+ * Per-posting contribution at query time: (value * idf[t]) * q_weight, fp32, summed per doc in the order the
  * query lists its terms.  Ascending term id is the CSR-row order of retrieval.py:72 / evaluate_rag_pipeline.py:117
  * (bit-identical to them); query-token order reproduces the pipeline twin's NumPy fallback
  * (evaluate_rag_pipeline.py:436-479).
@@ -75,18 +86,20 @@ typedef struct {
     int32_t val_type;  /* srx_val_type */
     int64_t n_docs;    /* shard-local rows */
     int64_t vocab;
-    int64_t nnz;
+    int64_t nnz;       /* real postings (sentinels not counted) */
+    int64_t n_blocks;  /* blocks of 4 padded postings (the trailing sentinel blocks not counted) */
     int64_t doc_base;  /* global row id of local row 0 (added to the ids srx_search returns) */
     int32_t tile_log2; /* G = 1 << tile_log2, <= SRX_MAX_TILE_LOG2 */
     int32_t n_tiles;   /* ceil(n_docs / G) */
+    int32_t unit_tiles; /* tiles per unit the runs are padded for (1..64) */
+    int32_t reserved0;
     const int64_t *term_ptr;  /* [vocab+1] */
-    const int32_t *post_doc;  /* [nnz + SRX_POST_PAD] */
-    const void *post_val;     /* [nnz + SRX_POST_PAD] f32 or f16 */
+    const int32_t *post;      /* [(n_blocks + SRX_BLOCK_PAD) * words per block] */
     const int32_t *tile_skip; /* [vocab*(n_tiles+1)] */
     const float *idf;         /* [vocab] */
-    const float *term_bound;  /* optional [vocab*4], may be NULL: the K-th largest post_val of each term in this shard for
+    const float *term_bound;  /* optional [vocab*4], may be NULL: the K-th largest stored value of each term in this shard for
                                  K = 1, 10, 100, 1000 (0 where the term has fewer than K postings).  Requires all
-                                 post_val >= 0.  Gives every query an exact lower bound on its k-th best score (a doc's
+                                 values >= 0.  Gives every query an exact lower bound on its k-th best score (a doc's
                                  score is at least any single contribution when all query idf are >= 0), which the
                                  kernels use as the initial top-k threshold. */
 } srx_index_desc;
@@ -95,14 +108,15 @@ typedef struct srx_index srx_index;
 
 /* Search-time tuning knobs; zero-initialise for defaults. */
 typedef struct {
-    int32_t supertile_log2; /* docs per unit = 2^supertile_log2 (>= tile_log2); 0 = auto */
+    int32_t supertile_log2; /* docs per unit = 2^supertile_log2 (>= tile_log2); 0 = the index's unit.  Any unit other than
+                             * the one the index was padded for is served by the tier-2 kernel alone (exact, slower) */
     int32_t target_blocks;  /* wave-sized work items to aim for (splits of a query / unsplit rounds + split tail); 0 = auto (3072) */
     int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
     int32_t reserved;       /* debug bits.  Exact results: 8 = every query through the tier-2 (block) kernel, 16 = ignore
                              * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only.  Timing
                              * experiments with WRONG results (bench ablations): 1 / 2 / 64 = skip candidate handling,
                              * 4 = loads only, 32 = no final ranking. */
-    int32_t unit_tiles;     /* docs per unit = unit_tiles * 2^tile_log2 (1..64, need not be a power of two); 0 = auto.
+    int32_t unit_tiles;     /* docs per unit = unit_tiles * 2^tile_log2 (1..64, need not be a power of two); 0 = the index's.
                                Takes precedence over supertile_log2. */
 } srx_search_opts;
 
@@ -173,9 +187,26 @@ int srx_merge_topk_packed_out(int32_t device, const int32_t *packed, int32_t nq,
 int srx_build_impacts(int32_t device, const float *tf, const int32_t *post_doc, const float *doc_len, int64_t nnz,
                       double k1, double b, double avgdl, float *out_impact, void *stream);
 
-/* tile_skip[t*(n_tiles+1)+j] = #postings of term t with doc < j<<tile_log2  (lower_bound per (t, j)). */
+/* Plain term-major arrays (term_ptr i64[vocab+1] offsets into post_doc, ascending doc inside a term):
+ * out_skip[t*(n_tiles+1)+j] = #postings of term t with doc < j<<tile_log2  (lower_bound per (t, j)) -- the UNPADDED
+ * skip table, an input of srx_build_blocks. */
 int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *post_doc, int64_t vocab,
                         int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
+
+/* Tiles per unit for a corpus of this density: the largest unit whose average per-term run still fits the tier-1
+ * kernel's registers with a 5-sigma margin and whose docs fit its 65536-bit bitmap.  Host-only, returns the value. */
+int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, int32_t tile_log2);
+
+/* Plain term-major arrays -> the blocked layout of srx_index_desc.  Inputs: term_ptr i64[vocab+1], post_term i32[nnz]
+ * (the term of every posting), post_doc i32[nnz], post_val f32|f16[nnz] (val_type), skip = srx_build_tile_skip's
+ * table, runpad i64[vocab*n_units+1] = exclusive prefix sum over (term, unit) of the run lengths rounded up to a
+ * multiple of 4 (n_units = ceil(n_tiles / unit_tiles); run length of (t, u) = skip[t][min((u+1)*unit_tiles, n_tiles)] -
+ * skip[t][u*unit_tiles]), n_blocks = runpad[last] / 4.  Outputs: out_post [(n_blocks + SRX_BLOCK_PAD) * words],
+ * out_skip i32[vocab*(n_tiles+1)] (padded positions), out_term_ptr i64[vocab+1]. */
+int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, const int32_t *post_term,
+                     const int32_t *post_doc, const void *post_val, const int32_t *skip, const int64_t *runpad,
+                     int64_t vocab, int64_t nnz, int32_t n_tiles, int32_t tile_log2, int32_t unit_tiles, int32_t *out_post,
+                     int32_t *out_skip, int64_t *out_term_ptr, int64_t n_blocks, void *stream);
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
 /* Dense INT8 side of the same service.  Replaces quantized_dot_product_batch

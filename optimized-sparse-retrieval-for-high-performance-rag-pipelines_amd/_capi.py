@@ -14,11 +14,12 @@ from typing import Optional
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libsparse_rx.so")
-SRC_PATH = os.path.join(_PKG_DIR, "csrc", "sparse_rx.hip")
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+SOURCES = ["wave_kernel.hip", "sparse_rx.hip", "dense.hip"]   # one translation unit each, compiled in parallel
+SRC_PATH = os.path.join(CSRC_DIR, "wave_kernel.hip")            # the dominant kernel's source (bench.py hashes it)
 INCLUDE_DIR = os.path.join(_ROOT, "include")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
-               "-std=c++17"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-std=c++17"]
 
 SRX_VAL_F32, SRX_VAL_F16 = 0, 1
 
@@ -33,10 +34,10 @@ class SparseRxError(RuntimeError):
 
 class IndexDesc(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("val_type", ctypes.c_int32), ("n_docs", ctypes.c_int64),
-                ("vocab", ctypes.c_int64), ("nnz", ctypes.c_int64), ("doc_base", ctypes.c_int64),
-                ("tile_log2", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("term_ptr", ctypes.c_void_p),
-                ("post_doc", ctypes.c_void_p), ("post_val", ctypes.c_void_p), ("tile_skip", ctypes.c_void_p),
-                ("idf", ctypes.c_void_p), ("term_bound", ctypes.c_void_p)]
+                ("vocab", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64), ("doc_base", ctypes.c_int64),
+                ("tile_log2", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("unit_tiles", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("term_ptr", ctypes.c_void_p), ("post", ctypes.c_void_p),
+                ("tile_skip", ctypes.c_void_p), ("idf", ctypes.c_void_p), ("term_bound", ctypes.c_void_p)]
 
 
 class SearchOpts(ctypes.Structure):
@@ -67,21 +68,44 @@ SYMBOLS = {
     "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
     "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "srx_auto_unit_tiles": (_I32, [_I64, _I64, _I64, _I32]),
+    "srx_build_blocks": (ctypes.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I64, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
 
 
+def _deps():
+    return [os.path.join(CSRC_DIR, f) for f in SOURCES] + [os.path.join(CSRC_DIR, "srx_common.h"),
+                                                            os.path.join(INCLUDE_DIR, "sparse_rx.h")]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/sparse_rx.hip for gfx950 with hipcc into <package>/libsparse_rx.so (in-tree)."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "sparse_rx.h"))):
+    """Compile csrc/*.hip for gfx950 with hipcc (one object per source, in parallel) and link them into
+    <package>/libsparse_rx.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps()):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise SparseRxUnavailable("hipcc not found: cannot build libsparse_rx.so")
-    cmd = [hipcc, *HIPCC_FLAGS, f"-I{INCLUDE_DIR}", "-o", LIB_PATH, SRC_PATH]
+    objdir = os.path.join(CSRC_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(os.path.join(CSRC_DIR, "srx_common.h")), os.path.getmtime(os.path.join(INCLUDE_DIR, "sparse_rx.h")))
+    procs, objs = [], []
+    for f in SOURCES:
+        src, obj = os.path.join(CSRC_DIR, f), os.path.join(objdir, f.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+            continue
+        cmd = [hipcc, *HIPCC_FLAGS, f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}", "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((f, subprocess.Popen(cmd)))
+    for f, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, f"hipcc -c {f}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB_PATH, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,516 @@
+// dense.hip -- the dense side of the same service: INT8 MFMA GEMM + fused top-k filter, and the f32
+// streaming matvec of search_by_vector.  Shares the block top-k machinery and the merge kernels (srx_common.h,
+// sparse_rx.hip).
+
+#include "srx_common.h"
+
+// The integer dot products are one MFMA GEMM (v_mfma_i32_32x32x32_i8, exact); the two scalings are done in fp64 like
+// the reference's NumPy scalars (int32 * float32 -> float64), so the stored fp32 score is the reference's bit for bit.
+// First form: the scaled scores go through HBM once (a [query batch][n_docs] fp32 matrix in the workspace) and the
+// block top-k machinery of the sparse path ranks each row; only scores > 0 are results (retriever_registry.py:519).
+// ================================================================================================
+namespace {
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate counters: one 128-byte line each (all waves
+                                      // add to these: counters sharing a line serialise in one L2 channel)
+
+// Query batch in MFMA-fragment order: apack[(tile * KS + s) * 64 + lane] = the 16 bytes lane `lane` feeds into k-step s
+// of query tile `tile` (row tile * 32 + (lane & 31), columns 32 s + 16 (lane >> 5) ..).  A wave's A load is then one
+// contiguous 1 KiB block instead of 32 scattered 32-byte segments (the request rate of the texture path was the limit).
+__global__ __launch_bounds__(THREADS) void srx_dense_pack_queries_kernel(const int8_t *__restrict__ queries, int nq, int dim,
+                                                                         v4i *__restrict__ apack) {
+    const int ks = dim / 32;
+    const int64_t n = (int64_t)((nq + 31) / 32) * ks * 64;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const int lane = (int)(i & 63);
+        const int64_t ts = i >> 6;
+        const int s = (int)(ts % ks);
+        const int q = (int)(ts / ks) * 32 + (lane & 31);
+        v4i x = {0, 0, 0, 0};
+        if (q < nq) x = *reinterpret_cast<const v4i *>(queries + (int64_t)q * dim + s * 32 + 16 * (lane >> 5));
+        apack[i] = x;
+    }
+}
+
+// One wave = 32 docs x (all queries, 32 at a time); a workgroup = 4 waves = 128 consecutive docs.  The wave keeps its
+// docs' B fragments in registers for the whole query loop (KS k-steps of 32: lane l holds corpus[d0 + (l & 31)]
+// [32 s + 16 (l >> 5) .. + 15], one 16-byte load); the queries' A fragments (the same map on the query rows) stream
+// from L2.  D[row = query][col = doc]: lane l holds doc l & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+template <int KS>
+__global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8_t *__restrict__ corpus,
+                                                                       const float *__restrict__ corpus_scale,
+                                                                       int64_t n_docs, const v4i *__restrict__ apack,
+                                                                       const float *__restrict__ query_scale, int nq,
+                                                                       float *__restrict__ scores, int64_t ld,
+                                                                       const int *__restrict__ gate) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
+    if (d0 >= n_docs) return;
+    if (gate != nullptr && *gate == 0) return;  // fallback pass: only runs when some query's candidate buffer overflowed
+    constexpr int DIM = KS * 32;
+    const int64_t d = d0 + r;
+    const bool dok = d < n_docs;
+    v4i B[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        B[s] = (v4i){0, 0, 0, 0};
+        if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+    }
+    const double ds = dok ? (double)corpus_scale[d] : 0.0;
+    for (int q0 = 0; q0 < nq; q0 += 32) {
+        const int qa = q0 + r;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[s], acc, 0, 0, 0);
+        }
+        // the tile's 32 query scales: one coalesced load, then a lane permute per accumulator row (a global load per
+        // row would put 16 dependent L1 round trips behind every tile)
+        const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const float qsr = __shfl(qs_mine, row);
+            if (dok && q0 + row < nq) scores[(int64_t)(q0 + row) * ld + d] = (float)(((double)acc[reg] * (double)qsr) * ds);
+        }
+    }
+}
+
+// The same GEMM with the top-k filter fused in: instead of writing the score, a lane keeps it only if it can still
+// reach the query's top k (score > 0 and >= tau[q], a valid lower bound of the k-th best score taken from a sample of
+// the corpus) and appends (doc, score) to the query's candidate buffer (one atomicAdd per query row and lane half).
+// A full buffer raises the query's overflow flag (the caller then re-ranks that query through the score matrix).
+template <int KS>
+__global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
+                                                                       const float *__restrict__ corpus_scale,
+                                                                       int64_t n_docs, const v4i *__restrict__ apack,
+                                                                       const float *__restrict__ query_scale, int nq,
+                                                                       const unsigned *__restrict__ tau, int cap,
+                                                                       int64_t doc_base, int32_t *__restrict__ buf_doc,
+                                                                       float *__restrict__ buf_score,
+                                                                       int *__restrict__ buf_cnt, int *__restrict__ ovf,
+                                                                       int *__restrict__ any_ovf) {
+    // DT doc tiles of 32 per wave: with two, every A fragment (query tile) read from L2 feeds two MFMAs; the B
+    // fragments of both tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
+    constexpr int DT = KS <= 12 ? 2 : 1;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (32 * DT);
+    if (d0 >= n_docs) return;
+    constexpr int DIM = KS * 32;
+    v4i B[DT][KS];
+    double ds[DT];
+    bool dok[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int64_t d = d0 + 32 * t + r;
+        dok[t] = d < n_docs;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            B[t][s] = (v4i){0, 0, 0, 0};
+            if (dok[t]) B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+        }
+        ds[t] = dok[t] ? (double)corpus_scale[d] : 0.0;
+    }
+    for (int q0 = 0; q0 < nq; q0 += 32) {
+        const int qa = q0 + r;
+        v16i acc[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][s], acc[t], 0, 0, 0);
+        }
+        // the tile's 32 query scales and thresholds: one coalesced load each, then a lane permute per accumulator row
+        const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
+        const unsigned tau_mine = qa < nq ? tau[qa] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            // Survivors of one 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator
+            // registers are in flight together -- one global round trip per tile instead of one per register with
+            // survivors: scores + pass bits; one atomicAdd per (query row, lane half) with survivors; broadcast the
+            // bases and store.
+            const int64_t d = d0 + 32 * t + r;
+            float scv[16];
+            unsigned passbits = 0;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // differs between the two lane halves
+                const float qsr = __shfl(qs_mine, row);
+                const unsigned taur = (unsigned)__shfl((int)tau_mine, row);
+                scv[reg] = dok[t] ? (float)(((double)acc[t][reg] * (double)qsr) * ds[t]) : 0.0f;
+                if (q0 + row < nq && scv[reg] > 0.0f && __float_as_uint(scv[reg]) >= taur) passbits |= 1u << reg;
+            }
+            if (__ballot(passbits != 0u) != 0ull) {  // uniform; about 6 survivors per tile at the design point
+                int basev[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool pass = (passbits >> reg) & 1u;
+                    const unsigned long long m = __ballot(pass);
+                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);  // my half's survivors: one query row
+                    basev[reg] = 0;
+                    if (pass && (mh & ((1u << r) - 1u)) == 0u)  // first survivor of the row reserves room for all of them
+                        basev[reg] = atomicAdd(&buf_cnt[(q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * DENSE_CNT_STRIDE], __popc(mh));
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const bool pass = (passbits >> reg) & 1u;
+                    const unsigned long long m = __ballot(pass);
+                    if (m != 0ull) {  // uniform
+                        const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);
+                        const int base = __shfl(basev[reg], h * 32 + (mh ? __ffs((int)mh) - 1 : 0));
+                        if (pass) {
+                            const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                            const int p = base + __popc(mh & ((1u << r) - 1u));
+                            if (p < cap) {
+                                buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d);
+                                buf_score[(int64_t)q * cap + p] = scv[reg];
+                            } else {
+                                ovf[q] = 1;
+                                *any_ovf = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Row top-k: one workgroup per (query, split of the doc range) folds its slice of the score row into an exact lazy
+// top-k list (topk_fold, the sparse path's machinery); the merge kernels rank the splits' lists.
+constexpr int DENSE_NPT = 16;
+// mode 0: rank scores[q][lo..hi) (ids = doc_base + column).  mode 1: rank the query's candidate buffer (buf_doc /
+// scores hold (doc, score) pairs, buf_cnt[q] of them).  only_flag: +1 = only queries with ovf[q] != 0, -1 = only queries
+// with ovf[q] == 0, 0 = all; a skipped query writes count -1 for its first list (the merge kernels then leave its
+// output row alone).  tau_out (optional): the k-th best score's bits when the list holds k entries, else 0.
+__global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_docs,
+                                                                 int nq, int k, int n_splits, int64_t doc_base, int mode,
+                                                                 const int32_t *__restrict__ buf_doc,
+                                                                 const int *__restrict__ buf_cnt, int cap,
+                                                                 const int *__restrict__ ovf, int only_flag,
+                                                                 const int *__restrict__ gate,
+                                                                 int32_t *__restrict__ cand_doc,
+                                                                 float *__restrict__ cand_score,
+                                                                 int32_t *__restrict__ cand_count,
+                                                                 unsigned *__restrict__ tau_out) {
+    __shared__ MergeShared M;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / n_splits, split = blockIdx.x - q * n_splits;
+    if (q >= nq) return;
+    if (gate != nullptr && *gate == 0) return;
+    if (only_flag != 0 && ((ovf[q] != 0) != (only_flag > 0))) {
+        if (tid == 0) cand_count[blockIdx.x] = split == 0 ? -1 : 0;
+        return;
+    }
+    int64_t total = n_docs;
+    if (mode == 1) total = min(buf_cnt[q * DENSE_CNT_STRIDE], cap);
+    const int64_t lo = total * split / n_splits, hi = total * (split + 1) / n_splits;
+    if (tid == 0) {
+        M.tk.count = 0;
+        M.tk.tau = 0;
+    }
+    __syncthreads();
+    const float *row = scores + (int64_t)q * ld;
+    const int32_t *drow = mode == 1 ? buf_doc + (int64_t)q * ld : nullptr;
+    for (int64_t c0 = lo; c0 < hi; c0 += (int64_t)THREADS * DENSE_NPT) {
+        unsigned ubits[DENSE_NPT];
+        int udoc[DENSE_NPT];
+        const unsigned tau = M.tk.tau;
+#pragma unroll
+        for (int n = 0; n < DENSE_NPT; ++n) {
+            const int64_t c = c0 + (int64_t)n * THREADS + tid;
+            float x = 0.0f;
+            int dd = 0;
+            if (c < hi) {
+                x = row[c];
+                dd = mode == 1 ? drow[c] : (int)(doc_base + c);
+            }
+            const unsigned b = __float_as_uint(x);
+            ubits[n] = (x > 0.0f && b >= tau) ? b : 0u;
+            udoc[n] = dd;
+        }
+        topk_fold<DENSE_NPT, true>(ubits, udoc, k, M.tk, M.hist);
+    }
+    __syncthreads();
+    topk_shrink(k, M.tk, M.hist);
+    const unsigned cnt = M.tk.count;
+    const int64_t o = (int64_t)blockIdx.x * k;
+    unsigned mn = 0xFFFFFFFFu;
+    for (unsigned i = tid; i < cnt; i += THREADS) {
+        cand_doc[o + i] = M.tk.doc[i];
+        cand_score[o + i] = __uint_as_float(M.tk.bits[i]);
+        mn = min(mn, M.tk.bits[i]);
+    }
+    if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
+    if (tau_out != nullptr) {  // n_splits == 1 here
+        const SumMaxMin rr = block_sum_max_min(0u, 0u, mn, M.tk.red);
+        if (tid == 0) tau_out[q] = cnt >= (unsigned)k ? rr.mn : 0u;
+    }
+}
+
+// Queries per pass: as many as keep the fallback's score matrix (queries x n_docs x 4 B) within 4 GiB, 32 .. 1024.
+// More queries per pass = the docs' B fragments are loaded once for more query tiles.
+int dense_qb(int64_t n_docs) {
+    int64_t q = (4ll << 30) / (((n_docs + 63) / 64 * 64) * 4);
+    q = q / 32 * 32;
+    if (q < 32) q = 32;
+    if (q > 1024) q = 1024;
+    return (int)q;
+}
+constexpr int DENSE_CAP = 65536;  // candidate buffer entries per query of the filtered path
+int dense_splits(int64_t n_docs, int nq, int k) {
+    int64_t s = 2048 / (nq > 0 ? nq : 1);  // >= 2048 workgroups when the batch is small
+    const int64_t by_docs = n_docs / (THREADS * DENSE_NPT * 4);
+    if (s > by_docs) s = by_docs;
+    const int64_t cap = (MERGE_NPT * THREADS) / (k > 0 ? k : 1);  // one merge level
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+// Sample size of the threshold pass: the k-th best score of S docs leaves about k * n_docs / S survivors per query;
+// aim at DENSE_CAP / 8.  0 = corpus too small for the filtered path to pay.
+int64_t dense_sample(int64_t n_docs, int k) {
+    int64_t S = (8 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
+    if (S < 16384) S = 16384;
+    S = (S + 127) / 128 * 128;
+    return (S * 4 <= n_docs) ? S : 0;
+}
+struct DenseWs {
+    float *scores;
+    int32_t *cand_doc;
+    float *cand_score;
+    int32_t *cand_count;
+    unsigned *tau;
+    int *buf_cnt, *ovf, *any_ovf;
+    int32_t *buf_doc;
+    float *buf_score;
+    v4i *apack;
+    int64_t bytes;
+};
+DenseWs dense_ws(void *base, int nq, int64_t n_docs, int k) {
+    const int QB = dense_qb(n_docs);
+    const int qb = nq < QB ? nq : QB;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, qb, k);
+    const bool filt = dense_sample(n_docs, k) > 0;
+    DenseWs w;
+    char *p = (char *)base;
+    auto take = [&](int64_t bytes) {
+        char *r = p;
+        p += (bytes + 255) / 256 * 256;
+        return r;
+    };
+    w.scores = (float *)take((int64_t)qb * ld * 4);
+    w.cand_doc = (int32_t *)take((int64_t)qb * ns * k * 4);
+    w.cand_score = (float *)take((int64_t)qb * ns * k * 4);
+    w.cand_count = (int32_t *)take((int64_t)qb * ns * 4);
+    w.tau = (unsigned *)take((int64_t)qb * 4);
+    w.buf_cnt = (int *)take((int64_t)(qb * DENSE_CNT_STRIDE + qb + 1) * 4);  // counts, overflow flags, any-overflow: one memset
+    w.ovf = w.buf_cnt + qb * DENSE_CNT_STRIDE;
+    w.any_ovf = w.ovf + qb;
+    w.buf_doc = (int32_t *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
+    w.buf_score = (float *)take(filt ? (int64_t)qb * DENSE_CAP * 4 : 0);
+    w.apack = (v4i *)take((int64_t)((qb + 31) / 32) * 32 * 1024);  // dim <= 1024 bytes per query row
+    w.bytes = (int64_t)(p - (char *)base) + 256;
+    return w;
+}
+}  // namespace
+
+SRX_API int64_t srx_dense_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_workspace_bytes: bad argument%s");
+    return dense_ws(nullptr, nq, n_docs, k).bytes;
+}
+
+SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                                const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                                int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                                int64_t workspace_bytes, void *stream_v) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: need n_docs > 0, 1 <= k <= 1024%s");
+    if (dim <= 0 || dim % 32 != 0 || dim > 1024)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be a multiple of 32, <= 1024 (pad the rows with zeros)%s");
+    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: doc_base + n_docs must fit int32%s");
+    if (nq == 0) return SRX_OK;
+    if (!corpus || !corpus_scale || !queries || !query_scale || !out_doc || !out_score || !out_count)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_i8: null pointer%s");
+    if (((uintptr_t)corpus | (uintptr_t)queries) & 15) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: corpus / queries must be 16-byte aligned%s");
+    const int64_t need = srx_dense_workspace_bytes(nq, n_docs, k);
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_i8: workspace too small%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int QB = dense_qb(n_docs);
+    const int qbmax = nq < QB ? nq : QB;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, qbmax, k);
+    const int64_t S = dense_sample(n_docs, k);
+    const DenseWs w = dense_ws(workspace, nq, n_docs, k);
+    auto blocks_for = [](int64_t docs) { return (unsigned)((docs + 32 * WAVES - 1) / (32 * WAVES)); };
+    int ks_ok = 1;
+    // KERNEL<KS> dispatch on dim / 32
+#define SRX_DENSE_DISPATCH(KERNEL, GRID, ...)                                                                         \
+    switch (dim / 32) {                                                                                               \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 24: hipLaunchKernelGGL(KERNEL<24>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        default: ks_ok = 0;                                                                                           \
+    }
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        const int qb = nq - q0 < QB ? nq - q0 : QB;
+        const int8_t *qp = queries + (int64_t)q0 * dim;
+        const float *qs = query_scale + q0;
+        int32_t *od = out_doc + (int64_t)q0 * k;
+        float *os = out_score + (int64_t)q0 * k;
+        int32_t *oc = out_count + q0;
+        const int *no_gate = nullptr;
+        hipLaunchKernelGGL(srx_dense_pack_queries_kernel, dim3(64), dim3(THREADS), 0, stream, qp, qb, (int)dim, w.apack);
+        if (S > 0) {
+            // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
+            HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(S), corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            if (!ks_ok) break;
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
+                               0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
+                               w.cand_score, w.cand_count, w.tau);
+            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (dim / 32 <= 12 ? blocks_for((n_docs + 1) / 2) : blocks_for(n_docs)), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.tau,
+                               DENSE_CAP, doc_base, w.buf_doc, w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
+                               n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, w.ovf, -1, no_gate, w.cand_doc,
+                               w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            int rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, 1, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                                (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
+            if (rc != SRX_OK) return rc;
+            // ---- fallback for queries whose buffer overflowed (degenerate score distributions): through the score
+            //      matrix; both kernels return at once unless the any-overflow flag is set ----
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld,
+                               (const int *)w.any_ovf);
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
+                               qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
+                               (const int *)w.any_ovf, w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                            (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
+            if (rc != SRX_OK) return rc;
+        } else {
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            if (!ks_ok) break;
+            hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
+                               qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
+                               w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+            HIP_TRY(hipGetLastError());
+            const int rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
+                                      (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
+            if (rc != SRX_OK) return rc;
+        }
+    }
+#undef SRX_DENSE_DISPATCH
+    if (!ks_ok) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be 32, 64, 96, 128, 192, 256, 384, 512, 768 or 1024 (pad the rows with zeros)%s");
+    return SRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense f32 side: RetrievalService.search_by_vector (rag_system/core/retrieval.py:402-436):
+// similarities = np.dot(embedding_index, query_vector), then the same top-k.  A matvec per query is HBM-bound (the
+// embedding matrix streams once per pass of up to 4 queries): one wave per doc row, the lane's slices of the queries
+// in registers, products summed in ascending column order per lane, then a fixed butterfly across lanes.  The BLAS
+// summation order of the reference is unspecified, so parity is to 1e-4 relative (north_star), not bit-exact.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int F32_QP = 4;    // queries per pass
+constexpr int F32_MAXS = 16; // dim <= 1024 = 16 slices of 64
+
+__global__ __launch_bounds__(THREADS) void srx_dense_f32_scores_kernel(const float *__restrict__ emb, int64_t n_docs, int dim,
+                                                                       const float *__restrict__ queries, int nqp,
+                                                                       float *__restrict__ scores, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int ns = dim >> 6;  // slices of 64 columns (dim is a multiple of 64)
+    float qv[F32_QP][F32_MAXS];
+#pragma unroll
+    for (int q = 0; q < F32_QP; ++q)
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) qv[q][i] = (q < nqp && i < ns) ? queries[(int64_t)q * dim + lane + 64 * i] : 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * WAVES;
+    for (int64_t d = wave; d < n_docs; d += n_waves) {
+        const float *row = emb + d * dim;
+        float r[F32_MAXS];
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) r[i] = i < ns ? row[lane + 64 * i] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < F32_QP; ++q) {
+            if (q < nqp) {  // uniform
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < F32_MAXS; ++i) a = a + r[i] * qv[q][i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o);
+                if (lane == 0) scores[(int64_t)q * ld + d] = a;
+            }
+        }
+    }
+}
+}  // namespace
+
+SRX_API int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_f32_workspace_bytes: bad argument%s");
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, F32_QP, k);
+    return (int64_t)F32_QP * ld * 4 + (int64_t)F32_QP * ns * k * 8 + (int64_t)F32_QP * ns * 4 + 1024;
+}
+
+SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
+                                 int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
+                                 void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: need n_docs > 0, 1 <= k <= 1024%s");
+    if (dim <= 0 || dim % 64 != 0 || dim > 64 * F32_MAXS)
+        return fail(SRX_ERR_INVALID, "srx_dense_search_f32: dim must be a multiple of 64, <= 1024 (pad the rows with zeros)%s");
+    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: doc_base + n_docs must fit int32%s");
+    if (nq == 0) return SRX_OK;
+    if (!emb || !queries || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: null pointer%s");
+    const int64_t need = srx_dense_f32_workspace_bytes(nq, n_docs, k);
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_f32: workspace too small%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int64_t ld = (n_docs + 63) / 64 * 64;
+    const int ns = dense_splits(n_docs, F32_QP, k);
+    float *scores = (float *)workspace;
+    int32_t *cand_doc = (int32_t *)(scores + (int64_t)F32_QP * ld);
+    float *cand_score = (float *)(cand_doc + (int64_t)F32_QP * ns * k);
+    int32_t *cand_count = (int32_t *)(cand_score + (int64_t)F32_QP * ns * k);
+    int64_t blocks = (n_docs + WAVES - 1) / WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    for (int q0 = 0; q0 < nq; q0 += F32_QP) {
+        const int qb = nq - q0 < F32_QP ? nq - q0 : F32_QP;
+        hipLaunchKernelGGL(srx_dense_f32_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, emb, n_docs, (int)dim,
+                           queries + (int64_t)q0 * dim, qb, scores, ld);
+        hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb, k,
+                           ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0,
+                           (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr);
+        HIP_TRY(hipGetLastError());
+        const int rc = srx_merge_impl(device, cand_doc, cand_score, cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1,
+                                  out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_count + q0, (int64_t)k, (int64_t)1,
+                                  nullptr, 0, stream_v);
+        if (rc != SRX_OK) return rc;
+    }
+    return SRX_OK;
+}
+
+#ifdef SRX_STAMP
+// Diagnostic build only: cumulative s_memtime ticks per kernel segment (see STAMP in srx_wave_kernel); resets.
+extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
+    return 0;
+}
+#endif

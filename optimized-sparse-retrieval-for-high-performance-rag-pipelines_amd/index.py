@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-POST_PAD = 16  # SRX_POST_PAD in include/sparse_rx.h
+BLOCK_PAD = 64  # SRX_BLOCK_PAD in include/sparse_rx.h: all-sentinel blocks behind the last run
 _TOKEN_RE = re.compile(r"\b\w+\b")
 
 
@@ -178,26 +178,38 @@ class DeviceIndex:
     ``srx_index`` handle.  All tensors are owned here (PyTorch-ROCm is the allocator); the library only
     keeps pointers."""
 
-    def __init__(self, term_ptr, post_doc, post_val, tile_skip, idf, n_docs: int, vocab: int, doc_base: int,
-                 tile_log2: int, device, term_bound=None, fine_bound=None):
+    def __init__(self, term_ptr, post, tile_skip, idf, n_docs: int, vocab: int, doc_base: int, tile_log2: int, device, *,
+                 nnz: int, n_blocks: int, unit_tiles: int, val_type: int, term_bound=None, fine_bound=None):
         torch = _torch()
         self.device = torch.device(device)
-        self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf = term_ptr, post_doc, post_val, tile_skip, idf
+        self.term_ptr, self.post, self.tile_skip, self.idf = term_ptr, post, tile_skip, idf
         self.term_bound = term_bound
         self.fine_bound = fine_bound  # [V, len(FINE_KS)]: the same statistic at more ranks K (sharded deployments combine these)
         self.n_docs, self.vocab, self.doc_base, self.tile_log2 = int(n_docs), int(vocab), int(doc_base), int(tile_log2)
         self.n_tiles = (self.n_docs + (1 << tile_log2) - 1) >> tile_log2
-        self.nnz = int(post_doc.numel()) - POST_PAD
-        self.val_type = _capi.SRX_VAL_F16 if post_val.dtype == torch.float16 else _capi.SRX_VAL_F32
-        d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
-                            nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
-                            term_ptr=_ptr(term_ptr), post_doc=_ptr(post_doc), post_val=_ptr(post_val),
-                            tile_skip=_ptr(tile_skip), idf=_ptr(idf), term_bound=_ptr(term_bound))
-        h = ctypes.c_void_p()
-        _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
-        self._h = h
+        self.nnz, self.n_blocks, self.unit_tiles, self.val_type = int(nnz), int(n_blocks), int(unit_tiles), int(val_type)
+        words = 8 if self.val_type == _capi.SRX_VAL_F32 else 6
+        if post.dtype != torch.int32 or post.numel() < (self.n_blocks + BLOCK_PAD) * words:
+            raise ValueError("post must be int32 and hold n_blocks + SRX_BLOCK_PAD blocks")
+        self._h = None
+        self._create_handle(term_bound)
         self._ws = None
         self._opts = _capi.SearchOpts()
+
+    @property
+    def value_bytes(self) -> int:
+        return 4 if self.val_type == _capi.SRX_VAL_F32 else 2
+
+    def _create_handle(self, table) -> None:
+        d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
+                            nnz=self.nnz, n_blocks=self.n_blocks, doc_base=self.doc_base, tile_log2=self.tile_log2,
+                            n_tiles=self.n_tiles, unit_tiles=self.unit_tiles, reserved0=0, term_ptr=_ptr(self.term_ptr),
+                            post=_ptr(self.post), tile_skip=_ptr(self.tile_skip), idf=_ptr(self.idf), term_bound=_ptr(table))
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
+        if self._h:
+            _capi.lib().srx_index_destroy(self._h)
+        self._h = h
 
     def set_term_bound(self, table) -> None:
         """Replace the score-bound table (f32[V, 4], K = 1, 10, 100, 1000).  Any table of valid LOWER bounds of the K-th
@@ -209,21 +221,14 @@ class DeviceIndex:
             assert tuple(table.shape) == (self.vocab, len(self.BOUND_KS))
         torch.cuda.synchronize(self.device)
         self.term_bound = table
-        d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
-                            nnz=self.nnz, doc_base=self.doc_base, tile_log2=self.tile_log2, n_tiles=self.n_tiles,
-                            term_ptr=_ptr(self.term_ptr), post_doc=_ptr(self.post_doc), post_val=_ptr(self.post_val),
-                            tile_skip=_ptr(self.tile_skip), idf=_ptr(self.idf), term_bound=_ptr(table))
-        h = ctypes.c_void_p()
-        _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
-        _capi.lib().srx_index_destroy(self._h)
-        self._h = h
+        self._create_handle(table)
         _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
 
     # -- construction ----------------------------------------------------------------------------------
     @classmethod
     def from_csr(cls, indptr, indices, data, idf, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14, score_bounds: bool = True) -> "DeviceIndex":
+                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0) -> "DeviceIndex":
         """Build from a doc-major CSR (host numpy or device torch arrays).
 
         mode "bm25": post_val = impact(tf, len) precomputed in fp32 (retrieval.py:58,70-71), idf as given.
@@ -250,15 +255,16 @@ class DeviceIndex:
             dl = None if doc_lengths is None else to_dev(doc_lengths, torch.float32)
             return cls.from_coo(rows, cols, vals, to_dev(idf, torch.float32), n_docs, doc_lengths=dl, k1=k1, b=b,
                                 avgdl=avgdl, mode=mode, val_dtype=val_dtype, device=dev, doc_base=doc_base,
-                                tile_log2=tile_log2, score_bounds=score_bounds)
+                                tile_log2=tile_log2, score_bounds=score_bounds, unit_tiles=unit_tiles)
 
     @classmethod
     def from_coo(cls, rows, cols, vals, idf, n_docs: int, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14, score_bounds: bool = True) -> "DeviceIndex":
+                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0) -> "DeviceIndex":
         """Build from device COO triples sorted by (row, col) -- i.e. the CSR's nnz order with explicit rows
         (rows i32 shard-local, cols i32, vals f32).  CSR -> CSC is one stable sort by term, which keeps rows
-        ascending inside a term."""
+        ascending inside a term; the term-major arrays are then scattered into the blocked layout of
+        include/sparse_rx.h (padded runs per unit of ``unit_tiles`` tiles; 0 = srx_auto_unit_tiles)."""
         torch = _torch()
         dev = torch.device(device)
         L = _capi.lib()
@@ -295,17 +301,33 @@ class DeviceIndex:
                 raise ValueError(f"unknown mode {mode!r}")
             fine_bound = cls._term_bounds(torch, cols_sorted, post_val, term_ptr, df, V) if score_bounds else None
             term_bound = None if fine_bound is None else fine_bound[:, [cls.FINE_KS.index(K) for K in cls.BOUND_KS]].contiguous()
-            del cols_sorted
-            # SRX_POST_PAD: the kernels read 4 postings per load and may run past the end of the last list
-            post_doc = torch.cat([post_doc, torch.zeros(POST_PAD, dtype=post_doc.dtype, device=dev)])[:nnz + POST_PAD]
-            post_val = torch.cat([post_val, torch.zeros(POST_PAD, dtype=post_val.dtype, device=dev)])[:nnz + POST_PAD]
             n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
-            tile_skip = torch.empty(V * (n_tiles + 1), dtype=torch.int32, device=dev)
+            # ---- unpadded tile skip table, then the blocked layout ----
+            skip = torch.empty(V * (n_tiles + 1), dtype=torch.int32, device=dev)
             _capi.check(L.srx_build_tile_skip(dev.index or 0, _ptr(term_ptr), _ptr(post_doc), V, n_tiles, tile_log2,
-                                              _ptr(tile_skip), stream), "srx_build_tile_skip")
+                                              _ptr(skip), stream), "srx_build_tile_skip")
+            if unit_tiles <= 0:
+                unit_tiles = _capi.check(L.srx_auto_unit_tiles(n_docs, V, nnz, tile_log2), "srx_auto_unit_tiles")
+            n_units = (n_tiles + unit_tiles - 1) // unit_tiles
+            edges = torch.arange(0, n_units + 1, device=dev, dtype=torch.int64).mul_(unit_tiles).clamp_(max=n_tiles)
+            at_units = skip.view(V, n_tiles + 1)[:, edges]                      # [V, n_units + 1]
+            run_len = (at_units[:, 1:] - at_units[:, :-1]).to(torch.int64)      # real postings per (term, unit)
+            runpad = torch.zeros(V * n_units + 1, dtype=torch.int64, device=dev)
+            runpad[1:] = torch.cumsum(((run_len + 3) & ~3).reshape(-1), 0)
+            del at_units, run_len, edges
+            n_blocks = int(runpad[-1].item()) // 4
+            val_type = _capi.SRX_VAL_F16 if post_val.dtype == torch.float16 else _capi.SRX_VAL_F32
+            words = 8 if val_type == _capi.SRX_VAL_F32 else 6
+            post = torch.empty((n_blocks + BLOCK_PAD) * words, dtype=torch.int32, device=dev)
+            tile_skip = torch.empty(V * (n_tiles + 1), dtype=torch.int32, device=dev)
+            term_ptr_pad = torch.empty(V + 1, dtype=torch.int64, device=dev)
+            _capi.check(L.srx_build_blocks(dev.index or 0, val_type, _ptr(term_ptr), _ptr(cols_sorted), _ptr(post_doc), _ptr(post_val),
+                                           _ptr(skip), _ptr(runpad), V, nnz, n_tiles, tile_log2, unit_tiles, _ptr(post),
+                                           _ptr(tile_skip), _ptr(term_ptr_pad), n_blocks, stream), "srx_build_blocks")
             torch.cuda.synchronize(dev)
-        return cls(term_ptr, post_doc, post_val, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, term_bound=term_bound,
-                   fine_bound=fine_bound)
+            del cols_sorted, skip, runpad, post_doc, post_val
+        return cls(term_ptr_pad, post, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, nnz=nnz, n_blocks=n_blocks,
+                   unit_tiles=unit_tiles, val_type=val_type, term_bound=term_bound, fine_bound=fine_bound)
 
     BOUND_KS = (1, 10, 100, 1000)  # the ranks K the engine looks up (include/sparse_rx.h: term_bound[vocab*4])
     FINE_KS = (1, 2, 4, 8, 10, 16, 32, 64, 100, 128, 256, 512, 1000, 1024)  # ... and the ranks kept for combining shards
@@ -339,29 +361,31 @@ class DeviceIndex:
 
     # -- native shard file -------------------------------------------------------------
     def save(self, path: str) -> None:
-        """Write this shard (postings, skip table, idf, bounds) to a native shard file (shardfile.py)."""
+        """Write this shard (blocked postings, skip table, idf, bounds) to a native shard file (shardfile.py)."""
         from . import shardfile
         torch = _torch()
         torch.cuda.synchronize(self.device)
-        arrays = {n: getattr(self, n).cpu().numpy() for n in ("term_ptr", "post_doc", "post_val", "tile_skip", "idf")}
+        arrays = {n: getattr(self, n).cpu().numpy() for n in ("term_ptr", "post", "tile_skip", "idf")}
         if self.term_bound is not None:
             arrays["term_bound"] = self.term_bound.cpu().numpy().reshape(-1)
         if self.fine_bound is not None:
             arrays["fine_bound"] = self.fine_bound.cpu().numpy().reshape(-1)
         shardfile.write_shard_file(path, arrays, {"n_docs": self.n_docs, "vocab": self.vocab, "nnz": self.nnz,
-                                                  "doc_base": self.doc_base, "tile_log2": self.tile_log2,
-                                                  "post_pad": POST_PAD})
+                                                  "n_blocks": self.n_blocks, "doc_base": self.doc_base,
+                                                  "tile_log2": self.tile_log2, "unit_tiles": self.unit_tiles,
+                                                  "val_type": self.val_type, "block_pad": BLOCK_PAD})
 
     @classmethod
     def load(cls, path: str, device="cuda:0", doc_base=None, verify: bool = True, chunk_bytes: int = 1 << 28) -> "DeviceIndex":
-        """Read a native shard file: memory-map it and stream every array to the GPU in chunks."""
+        """Read a native shard file: memory-map it, validate it (shardfile.read_shard_file) and stream every array to
+        the GPU in chunks."""
         from . import shardfile
         torch = _torch()
         if not torch.cuda.is_available():
             raise _capi.SparseRxUnavailable("no HIP device visible: DeviceIndex needs a GPU (there is no CPU fallback)")
         meta, arr = shardfile.read_shard_file(path, verify=verify)
-        if int(meta.get("post_pad", 0)) < POST_PAD:
-            raise ValueError(f"{path}: written with post_pad {meta.get('post_pad')}, this build needs {POST_PAD}")
+        if int(meta["block_pad"]) < BLOCK_PAD:
+            raise ValueError(f"{path}: written with block_pad {meta['block_pad']}, this build needs {BLOCK_PAD}")
         dev = torch.device(device)
 
         def up(a):
@@ -373,12 +397,11 @@ class DeviceIndex:
 
         with torch.cuda.device(dev):
             tb = up(arr["term_bound"]).view(-1, len(cls.BOUND_KS)) if "term_bound" in arr else None
-            fb = None
-            if "fine_bound" in arr and arr["fine_bound"].shape[0] == int(meta["vocab"]) * len(cls.FINE_KS):
-                fb = up(arr["fine_bound"]).view(-1, len(cls.FINE_KS))
-            return cls(up(arr["term_ptr"]), up(arr["post_doc"]), up(arr["post_val"]), up(arr["tile_skip"]), up(arr["idf"]),
-                       int(meta["n_docs"]), int(meta["vocab"]), int(meta["doc_base"] if doc_base is None else doc_base),
-                       int(meta["tile_log2"]), dev, term_bound=tb, fine_bound=fb)
+            fb = up(arr["fine_bound"]).view(-1, len(cls.FINE_KS)) if "fine_bound" in arr else None
+            return cls(up(arr["term_ptr"]), up(arr["post"]), up(arr["tile_skip"]), up(arr["idf"]), int(meta["n_docs"]),
+                       int(meta["vocab"]), int(meta["doc_base"] if doc_base is None else doc_base), int(meta["tile_log2"]), dev,
+                       nnz=int(meta["nnz"]), n_blocks=int(meta["n_blocks"]), unit_tiles=int(meta["unit_tiles"]),
+                       val_type=int(meta["val_type"]), term_bound=tb, fine_bound=fb)
 
     # -- search ----------------------------------------------------------------------------------------
     def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0,
@@ -458,7 +481,7 @@ class DeviceIndex:
         return {"wave_ms": ms[0], "block_ms": ms[1], "merge_ms": ms[2], "total_ms": ms[3], "calls": n}
 
     def device_bytes(self) -> int:
-        ts = [self.term_ptr, self.post_doc, self.post_val, self.tile_skip, self.idf] + ([self.term_bound] if self.term_bound is not None else [])
+        ts = [self.term_ptr, self.post, self.tile_skip, self.idf] + ([self.term_bound] if self.term_bound is not None else [])
         return sum(t.numel() * t.element_size() for t in ts)
 
     def close(self) -> None:

@@ -5,17 +5,18 @@ The reference only caches its host-side CSR (``.rag_cache/*.npz``, evaluate_rag_
 transposition, impacts and skip table at start-up, so the device index itself can be stored:
 
     magic "SRXSHARD" | u32 version | u32 header_len | u32 crc32(header JSON) | header JSON (utf-8) | padding to 4096 |
-    raw little-endian arrays, each starting at a multiple of 4096: term_ptr i64[V+1], post_doc i32[nnz+PAD],
-    post_val f32|f16[nnz+PAD], tile_skip i32[V*(n_tiles+1)], idf f32[V], term_bound f32[V*4] and fine_bound f32[V*14]
-    (both optional)
+    raw little-endian arrays, each starting at a multiple of 4096: term_ptr i64[V+1] (padded positions), post
+    i32[(n_blocks+PAD)*words] (blocks of 4 postings, docs and values side by side: include/sparse_rx.h), tile_skip
+    i32[V*(n_tiles+1)], idf f32[V], term_bound f32[V*4] and fine_bound f32[V*14] (both optional)
 
 The header carries the dims, dtypes, byte offsets and a CRC-32 of every array, and is itself covered by a CRC-32.
 Reading validates the header against itself BEFORE anything reaches the GPU -- the kernels index the arrays with these
 dims and receive raw pointers without sizes, so a damaged or mismatched header must become a ``ValueError`` here, never
-an out-of-bounds device read: every array length against the dims (term_ptr V+1, idf V, postings nnz + pad, skip table
-V x (n_tiles+1), bounds V x 4 / V x 14), term_ptr[0] == 0, term_ptr[V] == nnz and non-decreasing, offsets non-negative,
-aligned and non-overlapping; with ``verify`` also the array checksums, doc ids inside [0, n_docs) and the skip rows
-(non-decreasing, ending at the term's posting count).  Loading memory-maps the file and streams each array to the GPU in
+an out-of-bounds device read: every array length against the dims (term_ptr V+1, idf V, (n_blocks + pad) blocks of 8 or
+6 words, skip table V x (n_tiles+1), bounds V x 4 / V x 14), term_ptr a non-decreasing table of multiples of 4 from 0 to
+4 n_blocks, offsets non-negative, aligned and non-overlapping; with ``verify`` also the array checksums, doc ids inside
+[-2017, n_docs) (negative = sentinel) and the skip rows (non-decreasing, block-aligned at unit boundaries, ending at the term's
+padded posting count).  Loading memory-maps the file and streams each array to the GPU in
 bounded chunks (host memory stays small at 10^9 postings); nothing in the file is executed."""
 import json
 import os
@@ -26,9 +27,9 @@ from typing import Dict
 import numpy as np
 
 MAGIC = b"SRXSHARD"
-VERSION = 2
+VERSION = 3
 ALIGN = 4096
-_ARRAYS = ("term_ptr", "post_doc", "post_val", "tile_skip", "idf", "term_bound", "fine_bound")
+_ARRAYS = ("term_ptr", "post", "tile_skip", "idf", "term_bound", "fine_bound")
 _DTYPES = {"int64": np.int64, "int32": np.int32, "float32": np.float32, "float16": np.float16}
 
 
@@ -73,7 +74,7 @@ def write_shard_file(path: str, arrays: Dict[str, np.ndarray], meta: Dict) -> No
 
 
 FINE_KS_LEN = 14  # len(DeviceIndex.FINE_KS)
-_EXPECT_DTYPE = {"term_ptr": "int64", "post_doc": "int32", "tile_skip": "int32", "idf": "float32", "term_bound": "float32",
+_EXPECT_DTYPE = {"term_ptr": "int64", "post": "int32", "tile_skip": "int32", "idf": "float32", "term_bound": "float32",
                  "fine_bound": "float32"}
 
 
@@ -112,20 +113,26 @@ def read_shard_file(path: str, verify: bool = True):
     n_docs = _int_meta(path, meta, "n_docs", 1, 0x7FFFFFFE)
     vocab = _int_meta(path, meta, "vocab", 1, 1 << 40)
     nnz = _int_meta(path, meta, "nnz", 0, 1 << 40)
+    n_blocks = _int_meta(path, meta, "n_blocks", 0, 1 << 40)
     tile_log2 = _int_meta(path, meta, "tile_log2", 6, 14)
-    pad = _int_meta(path, meta, "post_pad", 0, 1 << 20)
+    unit_tiles = _int_meta(path, meta, "unit_tiles", 1, 64)
+    val_type = _int_meta(path, meta, "val_type", 0, 1)
+    pad = _int_meta(path, meta, "block_pad", 1, 1 << 20)
     _int_meta(path, meta, "doc_base", 0, 1 << 62)
+    if n_blocks * 4 < nnz:
+        raise ValueError(f"{path}: n_blocks = {n_blocks} cannot hold nnz = {nnz} postings")
+    words = 8 if val_type == 0 else 6
     n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
-    want = {"term_ptr": vocab + 1, "post_doc": nnz + pad, "post_val": nnz + pad, "tile_skip": vocab * (n_tiles + 1),
+    want = {"term_ptr": vocab + 1, "post": (n_blocks + pad) * words, "tile_skip": vocab * (n_tiles + 1),
             "idf": vocab, "term_bound": vocab * 4, "fine_bound": vocab * FINE_KS_LEN}
-    for name in ("term_ptr", "post_doc", "post_val", "tile_skip", "idf"):
+    for name in ("term_ptr", "post", "tile_skip", "idf"):
         if name not in entries:
             raise ValueError(f"{path}: array {name} is missing")
     out, spans = {}, []
     for name, e in entries.items():
         if name not in _ARRAYS or not isinstance(e, dict) or e.get("dtype") not in _DTYPES:
             raise ValueError(f"{path}: unknown array {name!r} / dtype {e.get('dtype') if isinstance(e, dict) else e!r}")
-        if name in _EXPECT_DTYPE and e["dtype"] != _EXPECT_DTYPE[name] or name == "post_val" and e["dtype"] not in ("float32", "float16"):
+        if e["dtype"] != _EXPECT_DTYPE[name]:
             raise ValueError(f"{path}: array {name} has dtype {e['dtype']}")
         dt = np.dtype(_DTYPES[e["dtype"]])
         count, off = e.get("count"), e.get("offset")
@@ -146,19 +153,20 @@ def read_shard_file(path: str, verify: bool = True):
             raise ValueError(f"{path}: arrays {an} and {bn} overlap")
     # ---- the offsets every kernel trusts ----
     tp = np.asarray(out["term_ptr"])
-    if int(tp[0]) != 0 or int(tp[-1]) != nnz or np.any(np.diff(tp) < 0):
-        raise ValueError(f"{path}: term_ptr is not a non-decreasing offset table from 0 to nnz = {nnz}")
+    if int(tp[0]) != 0 or int(tp[-1]) != 4 * n_blocks or np.any(np.diff(tp) < 0) or np.any(tp & 3):
+        raise ValueError(f"{path}: term_ptr is not a non-decreasing table of block-aligned positions from 0 to 4 * n_blocks = {4 * n_blocks}")
     if verify:
         for name, e in entries.items():
             if _crc(np.asarray(out[name])) != int(e.get("crc32", -1)):
                 raise ValueError(f"{path}: checksum mismatch in {name}")
-        chunk = 1 << 24
-        pd = out["post_doc"]
-        for i in range(0, nnz, chunk):
-            blk = np.asarray(pd[i: min(i + chunk, nnz)])
-            if blk.size and (int(blk.min()) < 0 or int(blk.max()) >= n_docs):
-                raise ValueError(f"{path}: post_doc holds doc ids outside [0, {n_docs})")
+        chunk = 1 << 22  # blocks per pass
+        blocks = out["post"].reshape(n_blocks + pad, words)
+        for i in range(0, n_blocks + pad, chunk):
+            docs = np.asarray(blocks[i: i + chunk, :4])
+            if docs.size and (int(docs.min()) < -1 - 32 * 63 or int(docs.max()) >= n_docs):
+                raise ValueError(f"{path}: post holds doc ids outside [-2017, {n_docs})")
         ts = np.asarray(out["tile_skip"]).reshape(vocab, n_tiles + 1)
-        if np.any(ts[:, 0] != 0) or np.any(np.diff(ts, axis=1) < 0) or np.any(ts[:, -1].astype(np.int64) != np.diff(tp)):
-            raise ValueError(f"{path}: tile_skip rows are not non-decreasing counts from 0 to the term's posting count")
+        if (np.any(ts[:, 0] != 0) or np.any(np.diff(ts, axis=1) < 0) or np.any(ts[:, -1].astype(np.int64) != np.diff(tp))
+                or np.any(ts[:, ::unit_tiles] & 3)):
+            raise ValueError(f"{path}: tile_skip rows are not non-decreasing, block-aligned at unit boundaries and ending at the term's padded posting count")
     return meta, out

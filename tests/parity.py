@@ -48,3 +48,50 @@ def assert_canonical_order(docs, scores, label=""):
     s = np.asarray(scores, dtype=np.float32)
     for i in range(1, len(s)):
         assert s[i - 1] > s[i] or (s[i - 1] == s[i] and d[i - 1] < d[i]), f"{label}: order violated at {i}"
+
+
+def np_build_blocks(indptr, indices, data, n_docs, vocab, tile_log2, unit_tiles, val_dtype=np.float32, block_pad=64):
+    """NumPy restatement of the blocked posting layout (include/sparse_rx.h, srx_index_desc) from a doc-major CSR whose
+    `data` are already the values to store.  Returns (term_ptr i64[V+1], post i32[(n_blocks+pad)*words],
+    tile_skip i32[V*(n_tiles+1)], n_blocks).  Slow, small cases only: the checker of srx_build_blocks."""
+    from scipy.sparse import csr_matrix
+    m = csr_matrix((np.asarray(data, np.float32), np.asarray(indices), np.asarray(indptr)), shape=(n_docs, vocab)).tocsc()
+    m.sort_indices()
+    G = 1 << tile_log2
+    n_tiles = (n_docs + G - 1) >> tile_log2
+    U = unit_tiles * G
+    n_units = (n_tiles + unit_tiles - 1) // unit_tiles
+    words = 8 if val_dtype == np.float32 else 6
+    term_ptr = np.zeros(vocab + 1, np.int64)
+    skip = np.zeros((vocab, n_tiles + 1), np.int32)
+    docs_out, vals_out = [], []
+    pos = 0
+    for t in range(vocab):
+        term_ptr[t] = pos
+        docs = m.indices[m.indptr[t]:m.indptr[t + 1]].astype(np.int64)
+        vals = m.data[m.indptr[t]:m.indptr[t + 1]]
+        start = pos
+        unit_start = {}
+        for u in range(n_units):
+            sel = (docs >= u * U) & (docs < (u + 1) * U)
+            unit_start[u] = pos - start
+            d, v = docs[sel], vals[sel]
+            padn = (-len(d)) % 4
+            docs_out.append(np.concatenate([d, np.full(padn, -1 - 32 * (t % 64), np.int64)]))
+            vals_out.append(np.concatenate([v, np.zeros(padn, np.float32)]))
+            pos += len(d) + padn
+        unit_start[n_units] = pos - start
+        for j in range(n_tiles + 1):
+            if j == n_tiles:
+                skip[t, j] = pos - start
+            else:
+                u = j // unit_tiles
+                skip[t, j] = unit_start[u] + int(((docs >= u * U) & (docs < j * G)).sum())
+    term_ptr[vocab] = pos
+    n_blocks = pos // 4
+    dd = np.concatenate(docs_out + [np.repeat(-1 - 32 * np.arange(block_pad, dtype=np.int64), 4)]).astype(np.int32).reshape(-1, 4)
+    vv = np.concatenate(vals_out + [np.zeros(4 * block_pad, np.float32)]).astype(val_dtype).reshape(-1, 4)
+    post = np.zeros((n_blocks + block_pad, words), np.int32)
+    post[:, :4] = dd
+    post[:, 4:] = vv.view(np.int32).reshape(n_blocks + block_pad, -1)
+    return term_ptr, post.reshape(-1), skip.reshape(-1), n_blocks

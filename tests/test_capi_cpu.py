@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libsparse_rx.so does not export {name}"
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
-    assert L.srx_version() == 100
+    assert L.srx_version() == 200
 
 
 def test_limits_and_error_strings():
@@ -115,23 +115,24 @@ def test_npz_cache_schema_roundtrip(golden_dir, tmp_path):
     assert np.array_equal(h2.idf.view(np.uint32), h.idf.view(np.uint32)) and h2.avgdl == np.float32(h.avgdl)
 
 
-def _consistent_shard(rng, V=37, n_docs=5000, tile_log2=11, pad=16, val_dtype=np.float16):
-    """Arrays of one small shard that satisfy every invariant read_shard_file checks."""
-    n_tiles = (n_docs + (1 << tile_log2) - 1) >> tile_log2
-    df = rng.integers(0, 60, V)
-    term_ptr = np.zeros(V + 1, np.int64)
-    term_ptr[1:] = np.cumsum(df)
-    nnz = int(term_ptr[-1])
-    post_doc = np.zeros(nnz + pad, np.int32)
-    tile_skip = np.zeros((V, n_tiles + 1), np.int32)
+def _consistent_shard(rng, V=37, n_docs=5000, tile_log2=11, unit_tiles=2, val_dtype=np.float16):
+    """Arrays of one small shard in the blocked layout that satisfy every invariant read_shard_file checks."""
+    from parity import np_build_blocks
+    rows, cols = [], []
     for t in range(V):
-        docs = np.sort(rng.choice(n_docs, df[t], replace=False)).astype(np.int32)
-        post_doc[term_ptr[t]:term_ptr[t + 1]] = docs
-        tile_skip[t] = np.searchsorted(docs, np.arange(n_tiles + 1) << tile_log2)
-    arrays = {"term_ptr": term_ptr, "post_doc": post_doc, "post_val": rng.random(nnz + pad).astype(val_dtype),
-              "tile_skip": tile_skip.reshape(-1), "idf": rng.random(V).astype(np.float32),
+        docs = np.sort(rng.choice(n_docs, rng.integers(0, 60), replace=False))
+        rows += docs.tolist()
+        cols += [t] * len(docs)
+    order = np.lexsort((cols, rows))
+    rows, cols = np.array(rows)[order], np.array(cols)[order]
+    indptr = np.zeros(n_docs + 1, np.int64)
+    indptr[1:] = np.cumsum(np.bincount(rows, minlength=n_docs))
+    vals = (rng.integers(1, 9, len(cols)) / 4).astype(np.float32)  # exact in fp16
+    term_ptr, post, skip, n_blocks = np_build_blocks(indptr, cols.astype(np.int32), vals, n_docs, V, tile_log2, unit_tiles, val_dtype)
+    arrays = {"term_ptr": term_ptr, "post": post, "tile_skip": skip, "idf": rng.random(V).astype(np.float32),
               "term_bound": rng.random(V * 4).astype(np.float32)}
-    meta = {"n_docs": n_docs, "vocab": V, "nnz": nnz, "doc_base": 123456789012, "tile_log2": tile_log2, "post_pad": pad}
+    meta = {"n_docs": n_docs, "vocab": V, "nnz": len(cols), "n_blocks": n_blocks, "doc_base": 123456789012, "tile_log2": tile_log2,
+            "unit_tiles": unit_tiles, "val_type": 1 if val_dtype == np.float16 else 0, "block_pad": 64}
     return arrays, meta
 
 
@@ -212,7 +213,10 @@ def test_shard_file_header_is_validated(tmp_path):
     # dims that disagree with the arrays (each would be an out-of-bounds device read)
     case(lambda h: h["meta"].__setitem__("vocab", meta["vocab"] + 1), "header dims require", verify=False)
     case(lambda h: h["meta"].__setitem__("n_docs", meta["n_docs"] * 4), "header dims require", verify=False)   # more tiles -> longer skip rows
-    case(lambda h: h["meta"].__setitem__("nnz", meta["nnz"] + 8), "header dims require", verify=False)
+    case(lambda h: h["meta"].__setitem__("n_blocks", meta["n_blocks"] + 8), "header dims require", verify=False)
+    case(lambda h: h["meta"].__setitem__("nnz", 4 * meta["n_blocks"] + 1), "cannot hold", verify=False)
+    case(lambda h: h["meta"].__setitem__("val_type", 1), "header dims require", verify=False)   # 6-word blocks: another array size
+    case(lambda h: h["meta"].__setitem__("unit_tiles", 0), "out of range", verify=False)
     case(lambda h: h["meta"].__setitem__("tile_log2", 9), "header dims require", verify=False)
     case(lambda h: h["meta"].__setitem__("tile_log2", 40), "out of range", verify=False)
     case(lambda h: h["meta"].pop("n_docs"), "missing or out of range", verify=False)
@@ -222,7 +226,7 @@ def test_shard_file_header_is_validated(tmp_path):
     case(lambda h: h["arrays"]["idf"].__setitem__("offset", 100), "negative or not", verify=False)
     case(lambda h: h["arrays"]["idf"].__setitem__("offset", h["arrays"]["term_ptr"]["offset"]), "overlap", verify=False)
     case(lambda h: h["arrays"]["idf"].__setitem__("offset", 1 << 40), "past the end", verify=False)
-    case(lambda h: h["arrays"]["post_doc"].__setitem__("dtype", "float32"), "dtype", verify=False)
+    case(lambda h: h["arrays"]["post"].__setitem__("dtype", "float32"), "dtype", verify=False)
     case(lambda h: h["arrays"].pop("tile_skip"), "missing", verify=False)
     # contents the kernels trust: term_ptr, doc ids, skip rows (the last two need the data pass of verify=True)
     def swap(a, b):
@@ -231,15 +235,15 @@ def test_shard_file_header_is_validated(tmp_path):
         return f
     bad_tp = dict(arrays)
     bad_tp["term_ptr"] = arrays["term_ptr"].copy()
-    bad_tp["term_ptr"][5] = bad_tp["term_ptr"][6] + 3  # decreasing
+    bad_tp["term_ptr"][5] = bad_tp["term_ptr"][6] + 4  # decreasing
     shardfile.write_shard_file(p, bad_tp, meta)
     with pytest.raises(ValueError, match="term_ptr"):
         shardfile.read_shard_file(p, verify=False)
     bad_doc = dict(arrays)
-    bad_doc["post_doc"] = arrays["post_doc"].copy()
-    bad_doc["post_doc"][3] = meta["n_docs"] + 7
+    bad_doc["post"] = arrays["post"].copy()
+    bad_doc["post"][3] = meta["n_docs"] + 7   # a doc slot of block 0
     shardfile.write_shard_file(p, bad_doc, meta)
-    with pytest.raises(ValueError, match="post_doc"):
+    with pytest.raises(ValueError, match="doc ids outside"):
         shardfile.read_shard_file(p)
     bad_ts = dict(arrays)
     bad_ts["tile_skip"] = arrays["tile_skip"].copy()

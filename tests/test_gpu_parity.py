@@ -137,10 +137,15 @@ def test_uniform_sparse_hash_path(rx):
     c = synth.uniform_corpus_np(200_000, 20_000, 40, seed=20252)
     _, idf, avgdl = synth.corpus_stats(c)
     q = synth.queries_np(256, c.vocab, 8, seed=77)
+    for ut in (1, 3, 5, 7):  # indexes padded for units of a non-power-of-two number of tiles (tier 1)
+        ixu = _dev_index(rx, c, idf, avgdl, tile_log2=12, unit_tiles=ut)
+        assert ixu.unit_tiles == ut
+        _assert_exact(ixu.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), f"uniform unit_tiles={ut}")
+        ixu.close()
     ix = _dev_index(rx, c, idf, avgdl, tile_log2=12)
-    for ut in (1, 3, 5, 7):  # units of a non-power-of-two number of tiles
+    for ut in (1, 3):  # search-time override of the unit: served by tier 2 alone, still exact
         ix.set_opts(unit_tiles=ut)
-        _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), f"uniform unit_tiles={ut}")
+        _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), f"uniform override unit_tiles={ut}")
     # target_blocks below the batch size: whole rounds of unsplit queries + a tail cut into 2 / 3 / 4 splits
     for sl, tb, dbg in ((0, 0, 0), (12, 0, 0), (16, 1, 0), (14, 100000, 0), (0, 0, 8), (17, 0, 8), (18, 0, 0), (0, 100, 0), (0, 60, 0),
                         (12, 250, 0), (0, 60, 8)):
@@ -297,6 +302,29 @@ def test_merge_topk_matches_single_shard(rx):
             assert torch.equal(rows[:, :k], d) and torch.equal(rows[:, k:2 * k], s.view(torch.int32)) and torch.equal(rows[:, 2 * k], n)
             _assert_exact((d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()), tuple(x[: nq_sub] for x in exp), f"packed tb={tb} nq={nq_sub}")
         ix.close()
+
+
+def test_blocked_layout_matches_numpy_builder(rx):
+    """srx_build_tile_skip + srx_build_blocks (device index construction) against the NumPy restatement of the blocked
+    layout (tests/parity.py): padded runs per unit, sentinels (doc -1, value 0), padded skip table and term offsets --
+    f32 and f16 values, units of 1 / 3 / 4 tiles, docs not a multiple of the tile, empty terms."""
+    from parity import np_build_blocks
+    from sparse_rx import synth
+    c = synth.zipf_corpus_np(7_013, 300, 20, seed=77)
+    idf = np.ones(c.vocab, np.float32)
+    for ut in (1, 3, 4):
+        for vd, npd in (("f32", np.float32), ("f16", np.float16)):
+            ix = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", val_dtype=vd, tile_log2=8, unit_tiles=ut)
+            tp, post, skip, nb = np_build_blocks(c.indptr, c.indices, c.data, c.n_docs, c.vocab, 8, ut, npd)
+            assert ix.n_blocks == nb and ix.nnz == len(c.indices) and ix.unit_tiles == ut
+            assert np.array_equal(ix.term_ptr.cpu().numpy(), tp), (ut, vd)
+            assert np.array_equal(ix.tile_skip.cpu().numpy(), skip), (ut, vd)
+            got = ix.post.cpu().numpy()
+            assert got.shape == post.shape and np.array_equal(got, post), (ut, vd)
+            ix.close()
+    auto = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", tile_log2=8)
+    assert 1 <= auto.unit_tiles <= 64 and (auto.unit_tiles << 8) <= 65536
+    auto.close()
 
 
 def test_impacts_bit_exact(rx):
@@ -492,14 +520,14 @@ def test_fuzz_shapes_vs_oracle(rx):
         terms = int(rng.integers(1, 65))
         q = synth.queries_np(nq, vocab, min(terms, vocab), seed=2000 + trial, dist="zipf" if s > 0 else "uniform", s=max(s, 0.5))
         tile_log2 = int(rng.integers(6, 13))
-        ix = _dev_index(rx, c, idf, avgdl, tile_log2=tile_log2)
         for _ in range(3):
             ut = int(rng.integers(1, 9))
             k = int(rng.choice([1, 5, 100, 128, 129, 300]))
-            ix.set_opts(unit_tiles=ut, target_blocks=int(rng.choice([0, 1, 10_000])))
+            ix = _dev_index(rx, c, idf, avgdl, tile_log2=tile_log2, unit_tiles=ut)  # runs padded for units of ut tiles
+            ix.set_opts(target_blocks=int(rng.choice([0, 1, 10_000])))
             _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k),
                           f"fuzz trial={trial} docs={n_docs} V={vocab} draws={draws} s={s} terms={terms} tile={tile_log2} ut={ut} k={k}")
-        ix.close()
+            ix.close()
 
 
 def test_shard_file_save_load(rx, tmp_path):
@@ -535,7 +563,7 @@ def test_shard_file_save_load(rx, tmp_path):
     new = _json.dumps(hdr, sort_keys=True).encode()
     assert (20 + len(new) + 4095) // 4096 == (20 + hlen + 4095) // 4096
     ds = (20 + hlen + 4095) // 4096 * 4096
-    bad = raw[:8] + struct.pack("<III", 2, len(new), zlib.crc32(new) & 0xFFFFFFFF) + new
+    bad = raw[:8] + struct.pack("<III", struct.unpack("<I", raw[8:12])[0], len(new), zlib.crc32(new) & 0xFFFFFFFF) + new
     open(p, "wb").write(bad + b"\0" * (ds - len(bad)) + raw[ds:])
     with pytest.raises(ValueError, match="header dims require"):
         rx.DeviceIndex.load(p)
