@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="dev: on one GPU, use the score bounds a shard would get among this many identical shards")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
+    ap.add_argument("--same-query", action="store_true", help="dev: every query of the batch is query 0 (postings stay in cache: the compute-bound time of the kernels)")
     ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
@@ -235,6 +236,10 @@ def main():
             q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=1.0)
         else:
             q_ptr, q_term, q_w = synth.queries_np(nq, V, w["terms"], seed=w["seed"] + 1, dist="zipf", s=w.get("zipf_s", 0.7), weights="learned")
+        if args.same_query:
+            n0 = int(q_ptr[1])
+            q_term, q_w = np.tile(q_term[:n0], nq), np.tile(q_w[:n0], nq)
+            q_ptr = (np.arange(nq + 1) * n0).astype(np.int32)
         # ---- corpus shard on the device (doc-major COO in CSR order), global statistics ---------------------------
         rows_l, cols_l, tf_l, dl_l = [], [], [], []
         gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]

@@ -114,8 +114,9 @@ typedef struct {
     int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
     int32_t reserved;       /* debug bits.  Exact results: 8 = every query through the tier-2 (block) kernel, 16 = ignore
                              * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only.  Timing
-                             * experiments with WRONG results (bench ablations): 1 / 2 / 64 = skip candidate handling,
-                             * 4 = loads only, 32 = no final ranking. */
+                             * experiments with WRONG results (bench ablations): 1 = no multi-term doc resolution, 2 = no
+                             * candidate screening, 4 = loads only, 32 = no final ranking, 512 = multi-term docs located but
+                             * not summed, 1024 = ... summed but not appended. */
     int32_t unit_tiles;     /* docs per unit = unit_tiles * 2^tile_log2 (1..64, need not be a power of two); 0 = the index's.
                                Takes precedence over supertile_log2. */
 } srx_search_opts;

@@ -432,7 +432,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     const int su_lo = (int)(((int64_t)n_super * split) / nsq);
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / nsq);
     // Tier 2 takes the whole query when tier 1 cannot serve it, otherwise only the units tier 1 flagged.
-    const bool all_units = (nt_all > W_MAXT) || (k > W_KMAX) || ((tpu << ix.tile_log2) > (1 << W_UNIT_LOG2)) || (dbg & 8);
+    const bool all_units = (nt_all > W_MAXT) || (k > W1_KMAX) || ((tpu << ix.tile_log2) > (1 << W_UNIT_LOG2)) || (dbg & 8);
     const unsigned *my_ovf = ovf + (int64_t)q * ovf_words;
     bool any = all_units && nt_all > 0;
     if (!all_units && nt_all > 0)
@@ -645,6 +645,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
 // an LDS list, the exact list selection of tier 1 shrinks it to k and the wave ranks and writes the row.
 constexpr int MW_CAP = 1024;
 struct MergeWaveShared {
+    static constexpr bool HIST_ALIASES_ZEROED_LDS = false;
     unsigned lbits[MW_CAP];
     int ldoc[MW_CAP];
     unsigned hist[256];

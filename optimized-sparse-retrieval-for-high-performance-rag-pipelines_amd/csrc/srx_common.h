@@ -62,14 +62,21 @@ constexpr int EMPTY_KEY = -1;
 constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 #ifndef SRX_W_R
-#define SRX_W_R 16
+#define SRX_W_R 12
 #endif
-constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8, 12 or 16)
-constexpr int W_WAVES_PER_EU = W_R <= 8 ? 4 : 3;  // what the register budget of that choice allows
+constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8, 12 or 16).  12: 128 VGPRs = 4 waves
+                                            // per SIMD with the 10 KB of LDS per wave (16 measured 2 % slower at 3 waves per SIMD)
+constexpr int W_WAVES_PER_EU = W_R <= 12 ? 4 : 3;  // what the register budget of that choice allows
 constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
 constexpr int W_DUPCAP = 48;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
 constexpr int W_LCAP = 384;                 // lazy top-k list capacity (entries; a multiple of 64)
-constexpr int W_KMAX = 128;                 // largest k served by tier 1
+constexpr int W_KMAX = 128;                 // largest k ranked by one wavefront (wave_rank_emit: 2 keys per lane)
+#ifndef SRX_W_LCAP
+#define SRX_W_LCAP 256
+#endif
+constexpr int W1_LCAP = SRX_W_LCAP;         // tier 1's lazy top-k list capacity (entries; a multiple of 64)
+constexpr int W1_KMAX = W1_LCAP - 64 - W_DUPCAP - 32 < W_KMAX ? W1_LCAP - 64 - W_DUPCAP - 32 : W_KMAX;  // largest k tier 1 serves: the list
+                                            // keeps room for a unit's multi-term docs, 64 appends and >= 32 entries between selections
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
 
 inline int fail(int code, const char *fmt, const char *detail = "") {
@@ -446,12 +453,6 @@ __device__ __forceinline__ void wsync() {
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-struct WaveShared {
-    unsigned lbits[W_LCAP];        // lazy top-k list (score bits, doc), unordered
-    int ldoc[W_LCAP];
-    unsigned hist[256];            // radix histogram of the list selection
-};
-
 // Exact k-th largest of the keys keyfn(i), i < count (key 0 = none; keys in [1, 2^31)); 8-bit MSD radix with a
 // 256-bin LDS histogram, 4 bins per lane.  The keys are re-read from LDS in every pass (a loop, not registers): the
 // selection is rare, and a small register footprint here is what keeps the calling kernel's VGPR count low (the
@@ -571,6 +572,10 @@ __device__ __noinline__ unsigned wave_list_select(SH &S, unsigned count, int k) 
         base += (unsigned)__popcll(m);
         wsync();
     }
+    if constexpr (SH::HIST_ALIASES_ZEROED_LDS) {  // the histogram borrowed words that must read as zero again (tier 1's doc bitmap)
+        reinterpret_cast<uint4 *>(S.hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        wsync();
+    }
     return T;
 }
 
@@ -584,7 +589,7 @@ __device__ __forceinline__ void wave_append(SH &S, WaveTopk &tk, int k, bool can
     const int lane = threadIdx.x;
     const unsigned long long m = __ballot(cand);
     if (m != 0ull) {  // uniform
-        if (tk.count > (unsigned)(W_LCAP - 64)) {  // make room for up to 64 more entries
+        if (tk.count > (unsigned)(SH::LCAP - 64)) {  // make room for up to 64 more entries
             tk.tau = uniu(wave_list_select(S, tk.count, k));
             tk.count = (unsigned)k;
         }

@@ -1,7 +1,7 @@
 // wave_kernel.hip -- tier 1 of the sparse search: ONE WAVEFRONT per (query, split), no barriers, no MFMA, no float atomics.
 //
 // Replaces simd_bm25_score + fast_topk_selection (rag_system/core/retrieval.py:41-92) / simd_tfidf_score
-// (rag_system/pipeline/evaluate_rag_pipeline.py:95-121) for queries of <= 64 terms at k <= 128.
+// (rag_system/pipeline/evaluate_rag_pipeline.py:95-121) for queries of <= 64 terms at k <= 112 (W1_KMAX).
 //
 // Layout it relies on (srx_common.h, IndexView): a term's postings are padded runs of 32-byte blocks
 // [4 docs | 4 values], one run per unit of <= 65536 docs; padding postings are sentinels (negative doc, value 0) and idle
@@ -24,21 +24,55 @@
 //     conservative per-lane threshold screens them; survivors get the exact fp32 test and go to a lazy LDS list that an
 //     exact wave-level radix select shrinks when it fills (srx_common.h).
 // Units that do not fit (a run longer than W_R / 4 blocks per lane, more than W_DUPCAP multi-term docs) are flagged
-// for tier 2, as are queries with > 64 terms and k > 128.
+// for tier 2, as are queries with > 64 terms and k > W1_KMAX.
 
 #include "srx_common.h"
 
+#ifdef SRX_STAMP
+#define CNT(i) (++st_cnt[i])
+#else
+#define CNT(i) \
+    do {       \
+    } while (0)
+#endif
+
 namespace {
 
+#ifndef SRX_W_WPE
+#define SRX_W_WPE W_WAVES_PER_EU
+#endif
+#ifndef SRX_W_DEPTH
+#define SRX_W_DEPTH 2  // register sets: units in flight + the one being scored
+#endif
 struct WaveShared2 {
-    unsigned bm[W_BM_WORDS];  // doc bitmap of the current unit; FIRST member: its byte offsets are the DS addresses
-    unsigned lbits[W_LCAP];   // lazy top-k list (score bits, doc), unordered
-    int ldoc[W_LCAP];
-    unsigned hist[256];       // radix histogram of the list selection
+    static constexpr int LCAP = W1_LCAP;
+    static constexpr bool HIST_ALIASES_ZEROED_LDS = true;
+    union {
+        unsigned bm[W_BM_WORDS];  // doc bitmap of the current unit; FIRST member: its byte offsets are the DS addresses
+        unsigned hist[256];       // radix histogram of the list selection: borrows the bitmap's first words (a selection only
+                                  // runs between units, when the bitmap is all zero) and zeroes them again when it is done
+    };
+    unsigned lbits[LCAP];         // lazy top-k list (score bits, doc), unordered
+    int ldoc[LCAP];
 };
 
+// d[rs] of lane src for a wave-uniform register index rs: a jump over v_readlane instructions
+template <int NR>
+__device__ __forceinline__ int lane_reg(const int (&d)[W_R], int rs, int src) {
+    switch (rs) {
+#define SRX_CASE(i) \
+    case i:         \
+        return __builtin_amdgcn_readlane(d[(i) < NR ? (i) : 0], src);
+        SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7) SRX_CASE(8) SRX_CASE(9) SRX_CASE(10)
+        SRX_CASE(11) SRX_CASE(12) SRX_CASE(13) SRX_CASE(14) SRX_CASE(15)
+#undef SRX_CASE
+        default:
+            return __builtin_amdgcn_readlane(d[0], src);
+    }
+}
+
 template <typename VT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_EU))) void srx_wave_kernel(const srx_wave_launch a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE))) void srx_wave_kernel(const srx_wave_launch a) {
     __shared__ WaveShared2 S;
     constexpr int BW = BlockWords<VT>::value;
     const IndexView &ix = a.ix;
@@ -51,7 +85,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
     const int t0 = a.q_ptr[q];
     const int nt = a.q_ptr[q + 1] - t0;
     const int tpu = ix.unit_tiles;
-    if (nt == 0 || nt > W_MAXT || k > W_KMAX || (tpu << ix.tile_log2) > (1 << W_UNIT_LOG2) || (a.dbg & 8)) {  // tier 2 serves it
+    if (nt == 0 || nt > W_MAXT || k > W1_KMAX || (tpu << ix.tile_log2) > (1 << W_UNIT_LOG2) || (a.dbg & 8)) {  // tier 2 serves it
         if (lane == 0) {
             a.cand_count[list] = 0;
             if (nt > 0) a.work[1 + atomicAdd(&a.work[0], 1)] = (int)blockIdx.x;
@@ -66,6 +100,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
     int sink = 0;            // debug only
+#ifdef SRX_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+    unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     bool flagged = false;    // wave-uniform: some unit of this block was handed to tier 2
     int lg = 0;
     while ((1 << lg) < nt) ++lg;
@@ -137,70 +175,94 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
         // (nothing emitted).
         auto process = [&](auto nrc, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> bool {
             constexpr int NR = decltype(nrc)::value;
-            if (tk.count > (unsigned)(W_LCAP - 64 - W_DUPCAP)) {  // uniform, rare: room for this unit's multi-term docs
+            if (tk.count > (unsigned)(WaveShared2::LCAP - 64 - W_DUPCAP)) {  // uniform, rare: room for this unit's multi-term docs
                 tk.tau = uniu(wave_list_select(S, tk.count, k));
                 tk.count = (unsigned)k;
             }
             // ---- pass 1: doc bits ----
-            unsigned adr[NR], old[NR], bit[NR];
+            unsigned adr[NR], t[NR];  // t[r] != 0: posting r found its doc's bit already set (an earlier posting matched the doc)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 adr[r] = ((unsigned)d[r] >> 3) & (unsigned)((W_BM_WORDS - 1) << 2);             // byte offset of word (doc >> 5) & 2047
                 unsigned one;  // min(value bits, 1): 0 for a value of exactly +0 (v_min_u32; the compiler's own form is cmp + cndmask)
                 asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(__float_as_uint(v[r])));
-                bit[r] = one << ((unsigned)d[r] & 31u);
-                old[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]), bit[r]);
+                const unsigned bit = one << ((unsigned)d[r] & 31u);
+                t[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]), bit) & bit;
             }
             unsigned acc = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) acc |= old[r] & bit[r];
+            for (int r = 0; r < NR; ++r) acc |= t[r];
             bool dense = false;
-            if (__ballot(acc != 0u) != 0ull) {  // uniform: some doc of this unit is matched by several terms (~2 units in 3 on C3)
-                const unsigned count0 = tk.count;
-                unsigned n_res = 0;
+            const bool anydup = __ballot(acc != 0u) != 0ull;
+            STAMP(2);  // wait for the unit's postings + pass 1
+            CNT(0);
+            if (anydup && !(a.dbg & 1)) {  // uniform: some doc of this unit is matched by several terms (~3 units in 4 on C3)
+                CNT(1);
+                // Lanes with a flagged posting (typically one or two) are visited one after the other: fm = the lane's
+                // flagged slots; the doc of its lowest flagged slot is broadcast, every lane picks up and blanks its
+                // posting of that doc (a doc occurs at most once per term, hence at most once per lane; sentinels carry
+                // negative docs), and the contributions are added in ascending lane order = the query's term order.
+                unsigned fm = 0;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    // postings that found their doc's bit set, still unresolved (v != 0)
-                    unsigned long long m = __ballot((old[r] & bit[r]) != 0u && v[r] != 0.0f);
-                    while (m != 0ull && !dense) {  // uniform loop, about one doc per unit on sparse queries
-                        const int src = __ffsll((long long)m) - 1;
-                        const int dd = __builtin_amdgcn_readlane(d[r], src);  // the doc, wave-uniform
-                        // A doc occurs at most once per term, hence at most once per lane (sentinels carry doc -1): pick up
-                        // my posting of it (if any) and blank it, so that the single-term screening below never sees it.
-                        float myv = 0.0f;
-#pragma unroll
-                        for (int r2 = 0; r2 < NR; ++r2) {
-                            const bool hit = d[r2] == dd;
-                            myv = hit ? v[r2] : myv;
-                            v[r2] = hit ? 0.0f : v[r2];
-                        }
-                        const float myc = 0.0f + (myv * my_idf) * my_qw;
-                        // exact score: contributions in the query's term order = ascending lane (term slots own lane groups)
-                        unsigned long long mm = __ballot(myv != 0.0f);
-                        float sum = 0.0f;
-                        while (mm != 0ull) {
-                            const int l2 = __ffsll((long long)mm) - 1;
-                            sum = sum + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(myc), l2));
-                            mm &= mm - 1ull;
-                        }
-                        const unsigned b = __float_as_uint(sum);
-                        if (sum > 0.0f && b >= tk.tau) {  // uniform; room for W_DUPCAP entries was made above
-                            if (lane == 0) {
-                                S.lbits[tk.count] = b;
-                                S.ldoc[tk.count] = dd;
-                            }
-                            ++tk.count;
-                        }
-                        if (++n_res > (unsigned)W_DUPCAP) dense = true;  // too many for this path: tier 2 takes the unit
-                        m = __ballot((old[r] & bit[r]) != 0u && v[r] != 0.0f);
-                    }
+                    unsigned one;
+                    asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(t[r]));
+                    fm |= one << r;
                 }
-                if (dense) tk.count = count0;  // nothing of this unit stays in the list
+                const unsigned count0 = tk.count;
+                unsigned n_res = 0;
+                unsigned long long m = __ballot(fm != 0u);
+                while (m != 0ull) {  // uniform loop: about two docs per such unit on C3
+                    const int src = __ffsll((long long)m) - 1;
+                    const unsigned fms = (unsigned)__builtin_amdgcn_readlane((int)fm, src);
+                    const int rs = __ffs((int)fms) - 1;                 // uniform: lane src's lowest flagged slot
+                    const int dd = lane_reg<NR>(d, rs, src);            // its doc, wave-uniform
+                    CNT(2);
+                    if (a.dbg & 512) {  // timing experiment: locate the docs only
+                        sink += dd;
+                        fm = (lane == src) ? (fm & (fm - 1u)) : fm;
+                        m = __ballot(fm != 0u);
+                        continue;
+                    }
+                    float myv = 0.0f;
+#pragma unroll
+                    for (int r2 = 0; r2 < NR; ++r2) {
+                        const bool hit = d[r2] == dd;
+                        myv = hit ? v[r2] : myv;
+                        v[r2] = hit ? 0.0f : v[r2];
+                    }
+                    const float myc = 0.0f + (myv * my_idf) * my_qw;
+                    unsigned long long mm = __ballot(myv != 0.0f);  // empty when an earlier visit resolved this doc (3 or more terms)
+                    float sum = 0.0f;
+                    while (mm != 0ull) {
+                        const int l2 = __ffsll((long long)mm) - 1;
+                        sum = sum + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(myc), l2));
+                        mm &= mm - 1ull;
+                    }
+                    const unsigned b = __float_as_uint(sum);
+                    if (sum > 0.0f && b >= tk.tau && !(a.dbg & 1024)) {  // uniform; room for W_DUPCAP entries was made above
+                        if (lane == 0) {
+                            S.lbits[tk.count] = b;
+                            S.ldoc[tk.count] = dd;
+                        }
+                        ++tk.count;
+                    }
+                    if (++n_res > (unsigned)W_DUPCAP) {  // too many for this path: tier 2 takes the unit, nothing of it stays in the list
+                        dense = true;
+                        tk.count = count0;
+                        break;
+                    }
+                    fm = (lane == src) ? (fm & (fm - 1u)) : fm;  // that slot is done
+                    m = __ballot(fm != 0u);
+                }
             }
+            STAMP(3);  // multi-term docs
             // ---- clear the bitmap words again ----
 #pragma unroll
             for (int r = 0; r < NR; ++r) *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]) = 0u;
+            STAMP(4);  // restore
             if (dense) return false;
+            if (a.dbg & 2) return true;  // timing experiment: no candidate screening (results are wrong)
             // ---- single-term docs.  Almost no posting can beat tau once the list has warmed up, so a conservative
             //      per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau, and
             //      > 0 so that blanked registers and sentinels never pass) screens them with one compare; the exact fp32
@@ -215,7 +277,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
 #pragma unroll
             for (int r = 1; r + 1 < NR; r += 2) vmax = fmaxf(fmaxf(vmax, v[r]), v[r + 1]);
             if constexpr (NR % 2 == 0) vmax = fmaxf(vmax, v[NR - 1]);
-            if (__ballot(vmax >= vthr) != 0ull) {  // uniform, rare after warm-up
+            const bool anycand = __ballot(vmax >= vthr) != 0ull;
+            STAMP(5);  // screening
+            if (anycand) {  // uniform, rare after warm-up
+                CNT(3);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const bool pass = v[r] >= vthr;
@@ -226,6 +291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
                     }
                 }
             }
+            STAMP(6);  // candidates (appends, selections)
             return true;
         };
 
@@ -234,20 +300,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
             flagged = true;
         };
 
-        // ---- software pipeline over units, unrolled by two (register sets A / B alternate): issue the loads of
-        //      unit u+1, then score unit u from registers ----
-        int dA[W_R], dB[W_R];
-        float vA[W_R], vB[W_R];
-        int b0 = bound(su_lo), b1 = bound(su_lo + 1), b2 = bound(su_lo + 2);  // b_j = boundary j; unit u = [b_u, b_{u+1})
-        int lenA = (su_lo < su_hi) ? b1 - b0 : 0, lenB = 0;
-        issue(b0, (__ballot(lenA > (W_R / 4) * LPT) == 0ull) ? lenA : 0, dA, vA);
-        // one stage: unit su is in (lenc, d, v); unit su+1 goes to (lenn, dn, vn)
-        auto stage = [&](int su, int lenc, int (&d)[W_R], float (&v)[W_R], int &lenn, int (&dn)[W_R],
-                         float (&vn)[W_R]) __attribute__((always_inline)) {
-            const int b3 = bound(su + 3);  // boundary needed two units from now (clamped to the row end)
-            lenn = (su + 1 < su_hi) ? b2 - b1 : 0;
-            const bool fitn = __ballot(lenn > (W_R / 4) * LPT) == 0ull;  // uniform: every term's run fits the steps
-            issue(b1, fitn ? lenn : 0, dn, vn);
+        // ---- software pipeline over units: SRX_W_DEPTH register sets rotate; while unit u is scored from registers, the
+        //      loads of units u+1 .. u+DEPTH-1 are in flight (a wave has no other way to keep memory requests outstanding:
+        //      with one unit ahead the data arrives long before the unit before it has been scored, and nothing is in
+        //      flight for the rest of that time) ----
+        // score unit su held in (d, v) with run length lenc (blocks)
+        auto score = [&](int su, int lenc, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
             if (a.dbg & 4) {  // timing experiment: loads only (results are wrong)
 #pragma unroll
                 for (int r = 0; r < W_R; ++r) sink += d[r] ^ (int)__float_as_uint(v[r]);
@@ -276,13 +334,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
                 }
                 if (!fine) flag_tier2(su);
             }
-            b1 = b2;
-            b2 = b3;
         };
+        // issue unit su's loads into (d, v); returns its run length (0 past the end; a run that does not fit loads nothing)
+        int bq[SRX_W_DEPTH + 2];  // bq[i] = boundary (next unit to issue) + i, in blocks
+        int su_issue = su_lo;
+#pragma unroll
+        for (int i = 0; i < SRX_W_DEPTH + 2; ++i) bq[i] = bound(su_lo + i);
+        auto fetch = [&](int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
+            const int len = (su_issue < su_hi) ? bq[1] - bq[0] : 0;
+            const bool fit = __ballot(len > (W_R / 4) * LPT) == 0ull;  // uniform: every term's run fits the steps
+            STAMP(0);  // loop overhead / previous tail
+            issue(bq[0], fit ? len : 0, d, v);
+            STAMP(1);  // issue
+#pragma unroll
+            for (int i = 0; i < SRX_W_DEPTH + 1; ++i) bq[i] = bq[i + 1];
+            ++su_issue;
+            bq[SRX_W_DEPTH + 1] = bound(su_issue + SRX_W_DEPTH + 1);  // needed SRX_W_DEPTH units from now (clamped to the row end)
+            return len;
+        };
+#if SRX_W_DEPTH == 2
+        int dA[W_R], dB[W_R];
+        float vA[W_R], vB[W_R];
+        int lenA = fetch(dA, vA), lenB = 0;
         for (int su = su_lo; su < su_hi; su += 2) {
-            stage(su, lenA, dA, vA, lenB, dB, vB);
-            if (su + 1 < su_hi) stage(su + 1, lenB, dB, vB, lenA, dA, vA);
+            lenB = fetch(dB, vB);
+            score(su, lenA, dA, vA);
+            if (su + 1 < su_hi) {
+                lenA = fetch(dA, vA);
+                score(su + 1, lenB, dB, vB);
+            }
         }
+#else
+        int dA[W_R], dB[W_R], dC[W_R];
+        float vA[W_R], vB[W_R], vC[W_R];
+        int lenA = fetch(dA, vA), lenB = fetch(dB, vB), lenC = 0;
+        for (int su = su_lo; su < su_hi; su += 3) {
+            lenC = fetch(dC, vC);
+            score(su, lenA, dA, vA);
+            if (su + 1 < su_hi) {
+                lenA = fetch(dA, vA);
+                score(su + 1, lenB, dB, vB);
+            }
+            if (su + 2 < su_hi) {
+                lenB = fetch(dB, vB);
+                score(su + 2, lenC, dC, vC);
+            }
+        }
+#endif
     };
     switch (6 - lg) {
         case 0: run(IntC<0>{}); break;
@@ -293,13 +391,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W_WAVES_PER_
         case 5: run(IntC<5>{}); break;
         default: run(IntC<6>{}); break;
     }
-    if ((a.dbg & 4) && sink == 0x7F123457) a.cand_count[list] = sink;  // keeps the loads of the timing experiment alive
+    if ((a.dbg & (4 | 512)) && sink == 0x7F123457) a.cand_count[list] = sink;  // keeps the loads of the timing experiment alive
     unsigned count = tk.count;
     if (a.dbg & 32) count = 0;  // timing experiment: no final selection / ranking
     if (count > (unsigned)k) {
         wave_list_select(S, count, k);
         count = (unsigned)k;
     }
+#ifdef SRX_STAMP
+    STAMP(7);  // epilogue (final select)
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+        atomicAdd(&g_stamp[8], 1ull);
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[9 + i], (unsigned long long)st_cnt[i]);
+    }
+#endif
     if (nsq == 1 && !flagged && a.out_doc != nullptr) {
         // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
         // the final row, so the merge kernel can skip the query.
@@ -333,3 +439,12 @@ int srx_launch_wave_kernel(const srx_wave_launch &a, int val_type, int64_t block
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
+
+#ifdef SRX_STAMP
+extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
+    return SRX_OK;
+}
+#endif

@@ -14,10 +14,10 @@ L = _capi.lib()
 out = (ctypes.c_ulonglong * 16)()
 L.srx_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 L.srx_debug_read_stamps(out)
-names = ["loop/prev tail", "issue", "wait data + pass1 + dup", "pass2+3", "restore", "multi park/resolve", "candidates", "epilogue"]
+names = ["loop / previous tail", "issue", "wait data + pass 1", "multi-term docs", "restore", "screening", "candidates", "epilogue"]
 tot = sum(out[i] for i in range(8))
 print("waves:", out[8], "ticks/wave:", tot / max(out[8], 1))
 w = max(out[8], 1)
-print(f"per wave: selects {out[9]/w:.2f}  append calls {out[10]/w:.2f}  appended {out[11]/w:.2f}  resolves {out[12]/w:.2f}  parked {out[13]/w:.2f}  tau updates {out[14]/w:.2f}")
+print(f"per wave: units {out[9]/w:.1f}  units with multi-term docs {out[10]/w:.1f}  docs resolved {out[11]/w:.1f}  screening triggers {out[12]/w:.1f}")
 for i, n in enumerate(names):
     print(f"{n:28s} {100.0 * out[i] / tot:6.2f} %   {out[i] / max(out[8],1):12.0f} ticks/wave")
