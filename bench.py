@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--same-query", action="store_true", help="dev: every query of the batch is query 0 (postings stay in cache: the compute-bound time of the kernels)")
+    ap.add_argument("--pipe-copy", action="store_true", help="host-batch pipeline: explicit H2D copy of the query block instead of zero-copy reads")
     ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
@@ -346,17 +347,22 @@ def main():
     # ---- PCIe-inclusive: the same steps fed from host batches through the pinned double-buffered pipeline ----------
     pcie_qps = pcie_ms = None
     if dist is None:
-        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=args.pipe_depth)
+        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=args.pipe_depth, zero_copy_queries=not args.pipe_copy)
         n_p = max(6, min(args.steps, 40))
         tickets = []
         for i in range(args.pipe_depth):  # warm-up (pinned buffers touched, streams created)
             pipe.result(pipe.submit(q_ptr, q_term, q_w))
         torch.cuda.synchronize(dev)
         t = time.perf_counter()
+        t_sub = t_res = 0.0
         for i in range(n_p):
+            ta = time.perf_counter()
             tickets.append(pipe.submit(q_ptr, q_term, q_w))
+            tb = time.perf_counter()
+            t_sub += tb - ta
             if len(tickets) == args.pipe_depth:
                 pd_, ps_, pc_ = pipe.result(tickets.pop(0))  # host arrays (views of the pinned result slot)
+                t_res += time.perf_counter() - tb
         while tickets:
             pd_, ps_, pc_ = pipe.result(tickets.pop(0))
         pcie_s = (time.perf_counter() - t) / n_p
@@ -364,9 +370,11 @@ def main():
         rd, rs, rc_ = (x.cpu().numpy() for x in res)
         if not args.debug and not (np.array_equal(pd_, rd) and np.array_equal(ps_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(pc_, rc_)):
             raise SystemExit("PARITY FAILURE: the host-batch pipeline returned rows that differ from the device-resident search")
+        log(f"[bench] host pipeline: submit {1e3 * t_sub / n_p:.3f} ms/batch, result wait {1e3 * t_res / n_p:.3f} ms/batch")
         log(f"[bench] PCIe-inclusive (host query batch in, host results out, pinned, {args.pipe_depth} slots): {pcie_qps:,.0f} queries/s "
             f"({pcie_ms:.3f} ms/step vs {1e3 * elapsed / args.steps:.3f} device-resident)")
-        ix.profile_read()
+        pp = ix.profile_read()
+        log(f"[bench] host pipeline: kernels in that loop: wave {pp['wave_ms']:.3f} ms, block {pp['block_ms']:.3f} ms, merge {pp['merge_ms']:.3f} ms per batch")
         pipe.close()
 
     # ---- roofline of the dominant kernel (this rank's scoring kernels) --------------------------------------------

@@ -209,6 +209,11 @@ int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, 
                      int64_t vocab, int64_t nnz, int32_t n_tiles, int32_t tile_log2, int32_t unit_tiles, int32_t *out_post,
                      int32_t *out_skip, int64_t *out_term_ptr, int64_t n_blocks, void *stream);
 
+/* hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream): the copy of a batch's result rows to pinned host memory (or
+ * of a query batch to the device) on a copy stream of the caller's, without going through a framework's stream guard
+ * (the host-side mirror measured ~1 ms per copy call that way: more than a whole C2 search). */
+int srx_memcpy_async(void *dst, const void *src, int64_t bytes, void *stream);
+
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
 /* Dense INT8 side of the same service.  Replaces quantized_dot_product_batch
  * (rag_system/core/retriever_registry.py:90-117; NumPy twin :538-548) + the top-k that follows it (:505-519):

@@ -68,6 +68,7 @@ SYMBOLS = {
     "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
     "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "srx_memcpy_async": (ctypes.c_int, [_VP, _VP, _I64, _VP]),
     "srx_auto_unit_tiles": (_I32, [_I64, _I64, _I64, _I32]),
     "srx_build_blocks": (ctypes.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I64, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),

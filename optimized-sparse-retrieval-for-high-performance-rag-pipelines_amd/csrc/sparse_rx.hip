@@ -25,6 +25,24 @@
 
 thread_local char srx_g_err[512] = "";
 
+#ifdef SRX_STAMP2
+__device__ unsigned long long g_stamp2[16];
+#define T2_T0() unsigned long long t2_prev = __builtin_amdgcn_s_memtime()
+#define T2(i)                                                                    \
+    do {                                                                         \
+        if (threadIdx.x == 0) {                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();           \
+            atomicAdd(&g_stamp2[i], t_ - t2_prev);                                \
+            t2_prev = t_;                                                        \
+        }                                                                        \
+    } while (0)
+#define T2C(i) do { if (threadIdx.x == 0) atomicAdd(&g_stamp2[i], 1ull); } while (0)
+#else
+#define T2_T0() do { } while (0)
+#define T2(i) do { } while (0)
+#define T2C(i) do { } while (0)
+#endif
+
 namespace {
 
 // Scoring kernel: one workgroup per (query, split of the doc range).
@@ -149,8 +167,12 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
     // batches of different terms (the next term may touch the same doc).  A tile's run [start, start + len) starts at
     // an arbitrary padded position: the batches cover the blocks from start & ~3 on, postings outside the run and
     // sentinels (doc -1) are blanked.
-    constexpr int NB = 8;                 // postings per thread per batch
-    constexpr int BATCH = THREADS * NB;   // 2048
+#ifndef SRX_DENSE_NB
+#define SRX_DENSE_NB 8
+#endif
+    constexpr int NB = SRX_DENSE_NB;      // postings per thread per batch (whole blocks of 4): with one batch ahead, 2 x NB x 8 bytes
+                                          // per thread are in flight (NB = 8 left the dense tiles latency-bound: profiles/r02_c5_*)
+    constexpr int BATCH = THREADS * NB;
     auto next_term = [&](int i) {  // first term index >= i with postings in this tile (uniform), nt if none
         while (i < nt && S.m_len[i] == 0) ++i;
         return i;
@@ -177,37 +199,64 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
     };
     auto add_batch = [&](int i, const int (&d)[NB], const float (&v)[NB]) {
         const float idf = S.m_idf[i], qw = S.m_qw[i];
+        // The postings of one batch belong to one term, so their docs are distinct: read all accumulators, then write
+        // them all (written as one loop of read-modify-writes the compiler has to assume the addresses may alias and
+        // serialises NB LDS round trips per batch -- the dense tiles' main stall before).
+        float acc_r[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) acc_r[r] = (d[r] >= 0) ? acc[d[r] - tile_base] : 0.0f;
 #pragma unroll
         for (int r = 0; r < NB; ++r)
-            if (d[r] >= 0) {
-                const int o = d[r] - tile_base;
-                acc[o] = acc[o] + (v[r] * idf) * qw;  // docs unique within a term: no conflict
-            }
+            if (d[r] >= 0) acc[d[r] - tile_base] = acc_r[r] + (v[r] * idf) * qw;
     };
-    int ci = next_term(0), co = 0;
-    if (ci >= nt) return;
-    int dA[NB], dB[NB];
-    float vA[NB], vB[NB];
-    load_batch(ci, co, dA, vA);
-    for (;;) {
-        // successor batch
-        int ni = ci, no = co + BATCH;
-        if (no >= span_of(ci)) {
-            ni = next_term(ci + 1);
+    // K batches in flight: register set j holds batch n with n % K == j; after batch n has been accumulated its set is
+    // refilled with batch n + K.  (One batch ahead left a many-term tile -- 50 terms of < 1 batch each -- paying one full
+    // memory round trip per term: profiles/r02_c4_*.)
+#ifndef SRX_DENSE_DEPTH
+#define SRX_DENSE_DEPTH 2
+#endif
+    constexpr int K = SRX_DENSE_DEPTH;
+    int qi[K], qo[K];  // term / offset of the batch in set j (qi == nt: none)
+    int dq[K][NB];
+    float vq[K][NB];
+    int ni = next_term(0), no = 0;  // the next batch to load
+    auto advance = [&]() {          // (ni, no) -> its successor in term-major order
+        no += BATCH;
+        if (no >= span_of(ni)) {
+            ni = next_term(ni + 1);
             no = 0;
         }
-        const bool more = ni < nt;
-        if (more) load_batch(ni, no, dB, vB);
-        add_batch(ci, dA, vA);
-        if (!more) break;
-        if (ni != ci) __syncthreads();
+    };
+    if (ni >= nt) return;
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            dA[r] = dB[r];
-            vA[r] = vB[r];
+    for (int j = 0; j < K; ++j) {
+        qi[j] = ni;
+        qo[j] = no;
+        if (ni < nt) {
+            load_batch(ni, no, dq[j], vq[j]);
+            advance();
         }
-        ci = ni;
-        co = no;
+    }
+    bool more = true;
+    while (more) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (more) {
+                if (qi[j] >= nt) {
+                    more = false;
+                } else {
+                    add_batch(qi[j], dq[j], vq[j]);
+                    const int nxt = qi[(j + 1) % K];  // term of the batch that is accumulated next
+                    if (nxt < nt && nxt != qi[j]) __syncthreads();  // next term: order the adds per doc
+                    qi[j] = ni;
+                    qo[j] = no;
+                    if (ni < nt) {
+                        load_batch(ni, no, dq[j], vq[j]);
+                        advance();
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
 }
@@ -394,26 +443,173 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
     return true;
 }
 
+// Exact k-th largest over n_items keys that STAY IN LDS (keyfn(i) re-reads them in every pass; key 0 = none, keys in
+// [1, 2^31)): MSD radix select with 8-bit digits, one histogram bin per thread (hist = 256 words).  The block-level
+// sibling of wave_radix_kth: no per-thread key arrays, so nothing spills (the register-array form radix_kth<N> cost the
+// dense tiles ~500 bytes of scratch per lane and as many HBM bytes as the postings themselves: profiles/r02_c5_*).
+// Requires 1 <= k <= #candidates; mx / mn = max / min candidate key.  Returns T; n_gt = #keys > T, n_eq = #keys == T.
+template <typename KeyFn>
+__device__ unsigned block_radix_kth_lds(KeyFn keyfn, unsigned n_items, unsigned k, unsigned mx, unsigned mn, unsigned n_cand,
+                                        unsigned *hist, unsigned *red, unsigned *n_gt, unsigned *n_eq) {
+    if (mx == mn) {
+        *n_gt = 0;
+        *n_eq = n_cand;
+        return mx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = 31 - __clz(mx ^ mn);
+    unsigned prefix = mx & ~((2u << hb) - 1u);
+    int shift = hb + 1;
+    unsigned krem = k, gt = 0, eq = 0;
+    while (shift > 0) {
+        const int w = shift < 8 ? shift : 8;
+        shift -= w;
+        const int hi_shift = shift + w;
+        hist[tid] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < n_items; i += THREADS) {
+            const unsigned x = keyfn(i);
+            if (x != 0 && ((x ^ prefix) >> hi_shift) == 0) atomicAdd(&hist[(x >> shift) & ((1u << w) - 1u)], 1u);
+        }
+        __syncthreads();
+        const unsigned sb = hist[tid];
+        unsigned suf = sb;  // inclusive suffix sum over threads >= tid
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_down(suf, o);
+            if (lane + o < 64) suf += v;
+        }
+        if (lane == 0) red[wave] = suf;
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww)
+            if (ww > wave) suf += red[ww];
+        const unsigned above = suf - sb;
+        if (above < krem && krem <= suf) {
+            red[8] = (unsigned)tid;
+            red[9] = above;
+            red[10] = sb;
+        }
+        __syncthreads();
+        const unsigned d = red[8], ab = red[9];
+        eq = red[10];
+        krem -= ab;
+        gt += ab;
+        prefix |= d << shift;
+        __syncthreads();
+    }
+    *n_gt = gt;
+    *n_eq = eq;
+    return prefix;
+}
+
+// Fold the positive accumulators of a dense tile into the block's running top-k.  The accumulators stay in LDS: a
+// counting pass, then either an append pass (the common case: the lazy list has room) or an exact selection over
+// (list U tile candidates) whose keys are re-read from LDS.
 __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
     const int G = 1 << ix.tile_log2;
-    unsigned ubits[NPT_DENSE];
-    int udoc[NPT_DENSE];
     const unsigned tau = S.tk.tau;
-#pragma unroll
-    for (int n = 0; n < NPT_DENSE; ++n) {
-        const int o = n * THREADS + tid;
-        float x = 0.f;
-        if (o < G) x = acc[o];
+    const unsigned n_old = S.tk.count;  // read BEFORE the barriers below
+    const int n_valid = (int)min((int64_t)G, ix.n_docs - (int64_t)tile_base);  // docs of this tile that exist
+    auto cand_key = [&](int o) -> unsigned {  // key of accumulator o: its score bits when it can enter the list, else 0
+        const float x = acc[o];
         const unsigned b = __float_as_uint(x);
-        const bool ok = x > 0.0f && b >= tau && (int64_t)tile_base + o < ix.n_docs;
-        ubits[n] = ok ? b : 0u;
-        udoc[n] = tile_base + o;
+        return (x > 0.0f && b >= tau) ? b : 0u;
+    };
+    unsigned mine = 0, lmx = 0, lmn = 0xFFFFFFFFu;
+    for (int o = tid; o < n_valid; o += THREADS) {
+        const unsigned x = cand_key(o);
+        if (x != 0u) {
+            ++mine;
+            lmx = max(lmx, x);
+            lmn = min(lmn, x);
+        }
     }
-    __syncthreads();  // accumulators are in registers; their LDS doubles as the radix histogram
-    topk_fold<NPT_DENSE, true>(ubits, udoc, k, S.tk, S.tbl);
+    const SumMaxMin r = block_sum_max_min(mine, lmx, lmn, S.tk.red);
+    const unsigned n_new = r.sum;
+    if (n_new == 0 && n_old <= (unsigned)k) return;  // uniform
+    if (n_old + n_new <= (unsigned)KMAX) {  // room in the lazy list: append
+        for (int o = tid; o < n_valid; o += THREADS) {
+            const unsigned x = cand_key(o);
+            if (x != 0u) {
+                const unsigned p = atomicAdd(&S.tk.count, 1u);
+                S.tk.bits[p] = x;
+                S.tk.doc[p] = tile_base + o;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- selection over (list U candidates) ----
+    unsigned *hist = reinterpret_cast<unsigned *>(S.st_off);  // 256 words: the hash path's step table is idle here
+    unsigned omx = 0, omn = 0xFFFFFFFFu;
+    for (unsigned i = tid; i < n_old; i += THREADS) {
+        omx = max(omx, S.tk.bits[i]);
+        omn = min(omn, S.tk.bits[i]);
+    }
+    const SumMaxMin r1 = block_sum_max_min(0u, max(omx, r.mx), min(omn, r.mn), S.tk.red);
+    const unsigned n_items = n_old + (unsigned)n_valid;
+    auto key1 = [&](unsigned i) -> unsigned { return i < n_old ? S.tk.bits[i] : cand_key((int)(i - n_old)); };
+    auto doc_of = [&](unsigned i) -> int { return i < n_old ? S.tk.doc[i] : tile_base + (int)(i - n_old); };
+    unsigned n_gt, n_eq;
+    const unsigned T = block_radix_kth_lds(key1, n_items, (unsigned)k, r1.mx, r1.mn, n_old + n_new, hist, S.tk.red, &n_gt, &n_eq);
+    const unsigned need = (unsigned)k - n_gt;  // ties to accept, 1 <= need <= n_eq
+    unsigned T2 = 0;                            // accept ties with 0x7FFFFFFF - doc >= T2 (smaller docs first)
+    if (n_eq > need) {
+        auto key2 = [&](unsigned i) -> unsigned { return key1(i) == T ? 0x7FFFFFFFu - (unsigned)doc_of(i) : 0u; };
+        unsigned mx2 = 0, mn2 = 0xFFFFFFFFu;
+        for (unsigned i = tid; i < n_items; i += THREADS) {
+            const unsigned x = key2(i);
+            if (x != 0u) {
+                mx2 = max(mx2, x);
+                mn2 = min(mn2, x);
+            }
+        }
+        const SumMaxMin r2 = block_sum_max_min(0u, mx2, mn2, S.tk.red);
+        unsigned g2, e2;
+        T2 = block_radix_kth_lds(key2, n_items, need, r2.mx, r2.mn, n_eq, hist, S.tk.red, &g2, &e2);
+    }
+    // rebuild the list: the old entries first go to registers (KPT per thread), then everything that survives is appended
+    unsigned okey[KPT];
+    int odoc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const unsigned i = tid + j * THREADS;
+        okey[j] = i < n_old ? S.tk.bits[i] : 0u;
+        odoc[j] = i < n_old ? S.tk.doc[i] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        S.tk.count = 0;
+        S.tk.tau = T;
+    }
+    __syncthreads();
+    auto keep = [&](unsigned x, int d) { return x != 0u && (x > T || (x == T && (0x7FFFFFFFu - (unsigned)d) >= T2)); };
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+        if (keep(okey[j], odoc[j])) {
+            const unsigned p = atomicAdd(&S.tk.count, 1u);
+            S.tk.bits[p] = okey[j];
+            S.tk.doc[p] = odoc[j];
+        }
+    // candidates below the OLD tau were already excluded by cand_key (tau captured above); T >= that tau
+    for (int o = tid; o < n_valid; o += THREADS) {
+        const unsigned x = cand_key(o);
+        if (keep(x, tile_base + o)) {
+            const unsigned p = atomicAdd(&S.tk.count, 1u);
+            S.tk.bits[p] = x;
+            S.tk.doc[p] = tile_base + o;
+        }
+    }
+    __syncthreads();
 }
+
+#ifndef SRX_DENSE_MIN
+#define SRX_DENSE_MIN 4096
+#endif
+constexpr int DENSE_MIN = SRX_DENSE_MIN < HASH_CAP ? SRX_DENSE_MIN : HASH_CAP;  // a tile with more postings than this is accumulated densely
 
 template <typename VT>
 __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const int32_t *__restrict__ q_ptr,
@@ -422,6 +618,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                             int ovf_words, int lists_per_q, int32_t *__restrict__ cand_doc,
                             float *__restrict__ cand_score, int32_t *__restrict__ cand_count) {
     const int tid = threadIdx.x;
+    T2_T0();
     int q, split, nsq;
     decode_item(bid, n_whole, n_splits, q, split, nsq);
     if (q >= nq) return;
@@ -503,18 +700,22 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     S.m_len[tid] = my_len;
                 }
                 __syncthreads();
+                T2(0);
                 served = flat_tile<VT>(S, ix, nt, my_len, su << ix.tile_log2, k);
+                T2(1); T2C(9);
                 for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                 __syncthreads();
             }
             if (served) {
-            } else if (P > 0 && P <= (unsigned)HASH_CAP) {
+            } else if (P > 0 && P <= (unsigned)DENSE_MIN) {
                 if (tid < nt) {
                     S.m_start[tid] = base + lo;
                     S.m_len[tid] = my_len;
                 }
                 __syncthreads();
+                T2(0);
                 hash_unit<VT>(S, ix, nt, my_len, k, dbg);
+                T2(2); T2C(10);
             } else if (P > 0) {
                 // ---- overflow: pack this supertile's tiles greedily into units of <= HASH_CAP postings;
                 //      a single tile above that is accumulated densely ----
@@ -537,7 +738,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     S.grp[0] = 0;
                     for (int j = 0; j < nt_tiles; ++j) {
                         const int pj = S.ptile[j];
-                        if (acc_p > 0 && acc_p + pj > HASH_CAP) {
+                        if (acc_p > 0 && acc_p + pj > DENSE_MIN) {
                             S.grp[++ng] = j;
                             acc_p = 0;
                         }
@@ -563,12 +764,17 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                         S.m_len[tid] = glen;
                     }
                     __syncthreads();
-                    if (GP <= (unsigned)HASH_CAP) {
+                    if (GP <= (unsigned)DENSE_MIN) {
+                        T2(0);
                         hash_unit<VT>(S, ix, nt, glen, k, dbg);
+                        T2(2); T2C(10);
                     } else {  // one dense tile (gb == ga + 1 by construction)
                         const int tile_base = ga << ix.tile_log2;
+                        T2(0);
                         dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
+                        T2(3); T2C(11);
                         dense_tile_select(S, ix, tile_base, k);
+                        T2(4);
                         for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                         __syncthreads();
                     }
@@ -603,7 +809,9 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
 
     // ---- emit this split's list (unordered; the merge kernel ranks) ----
     __syncthreads();
+    T2(0);
     topk_shrink(k, S.tk, S.tbl);
+    T2(5); T2C(12);
     const unsigned cnt = S.tk.count;
     const int64_t o = list * k;
     for (unsigned i = tid; i < cnt; i += THREADS) {
@@ -1296,6 +1504,13 @@ SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const i
 // Dense INT8 side of the same service: quantized_dot_product_batch
 // (rag_system/core/retriever_registry.py:90-117; NumPy twin :538-548) + the same top-k (:505-519).
 
+SRX_API int srx_memcpy_async(void *dst, const void *src, int64_t bytes, void *stream_v) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(SRX_ERR_INVALID, "srx_memcpy_async: bad argument%s");
+    if (bytes == 0) return SRX_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream_v));
+    return SRX_OK;
+}
+
 SRX_API int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, int32_t tile_log2) {
     if (n_docs <= 0 || vocab <= 0 || nnz < 0 || tile_log2 < 6 || tile_log2 > SRX_MAX_TILE_LOG2)
         return fail(SRX_ERR_INVALID, "srx_auto_unit_tiles: bad argument%s");
@@ -1351,3 +1566,12 @@ SRX_API int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *te
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
+
+#ifdef SRX_STAMP2
+SRX_API int srx_debug_read_stamps2(unsigned long long *h_out16) {
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp2), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(z)));
+    return SRX_OK;
+}
+#endif

@@ -435,10 +435,12 @@ class DeviceIndex:
             _capi.check(rc, "srx_search")
         return out
 
-    def search_packed_device(self, q_ptr, q_term, q_weight, k: int, out=None):
+    def search_packed_device(self, q_ptr, q_term, q_weight, k: int, out=None, stream=None, workspace=None):
         """``srx_search_packed``: the same search, each query's result written as one row
         [k doc ids][k score bit patterns][count] of ``out`` (i32[nq, 2k+1], contiguous) -- the exchange format of the
-        sharded search, so no packing kernel runs.  Returns ``out``."""
+        sharded search, so no packing kernel runs.  Returns ``out``.  ``stream`` (a torch stream, default: the current
+        one) and ``workspace`` (a uint8 tensor of ``workspace_bytes`` bytes, default: the index's own) let several
+        searches of one index be in flight on different streams."""
         torch = _torch()
         nq = q_ptr.numel() - 1
         if not (1 <= k <= _capi.limits()["max_k"]):
@@ -447,16 +449,16 @@ class DeviceIndex:
             if out is None:
                 out = torch.empty((nq, 2 * k + 1), dtype=torch.int32, device=self.device)
             assert out.dtype == torch.int32 and tuple(out.shape) == (nq, 2 * k + 1) and out.is_contiguous()
-            need = self.workspace_bytes(nq, k)
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            if workspace is None:
+                need = self.workspace_bytes(nq, k)
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+                workspace = self._ws
+            sp = stream.cuda_stream if stream is not None else _stream_ptr(torch, self.device)
             rc = _capi.lib().srx_search_packed(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out),
-                                               _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+                                               _ptr(workspace), workspace.numel(), sp)
             _capi.check(rc, "srx_search_packed")
         return out
-
-    def validate_queries(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> None:
-        validate_query_batch(q_ptr, q_term, q_weight, self.vocab)
 
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
         """Host arrays in, host arrays out (doc, score, count).  The batch is validated first (``validate_queries``);
@@ -500,36 +502,44 @@ class HostBatchPipeline:
     """Host batches in, host rows out, with the PCIe copies off the critical path (the metric's batch
     wall time includes the H2D of the query batch and the D2H of the nq x k results).
 
-    Per slot (``depth`` of them, 2 = double buffering): a pinned host staging buffer and a device buffer for the query
-    CSR (q_ptr | q_term | q_weight packed into one int32 block: ONE H2D copy), a device block of packed result rows
-    [k doc ids][k score bits][count] written directly by ``srx_search_packed`` and a pinned host block for them (ONE
-    D2H copy).  H2D runs on its own HIP stream, the search on the caller's current stream, D2H on a third stream,
-    ordered by events; so while batch i is being scored, batch i+1 is uploading and batch i-1 is downloading.
-    ``submit`` returns a ticket at once; ``result(ticket)`` waits for that batch's D2H and returns NumPy views of the
-    pinned rows (valid until the slot is reused ``depth`` submits later)."""
+    ``depth`` slots (3 = triple buffering), each with its own HIP stream, pinned host staging for the query CSR
+    (q_ptr | q_term | q_weight packed into one int32 block), a device block of packed result rows
+    [k doc ids][k score bits][count] written directly by ``srx_search_packed``, a pinned host block for them and its own
+    search workspace.  A batch's work -- (H2D of the query block,) search, ONE D2H copy of the rows -- is submitted to
+    its slot's stream in order, so nothing has to be ordered across streams (no events: an event record / wait pair
+    costs ~0.15 ms of host time on this stack, a stream-guarded tensor copy ~1 ms), while batches of different slots
+    overlap on the GPU: batch i+1 is scored while batch i's rows travel to the host.  By default the kernels read the
+    query block straight from the pinned (device-mapped) staging buffer (``zero_copy_queries``): a few hundred KB
+    touched once, no copy call at all.  ``submit`` returns a ticket at once; ``result(ticket)`` waits for that slot's
+    stream and returns NumPy views of the pinned rows (valid until the slot is reused ``depth`` submits later)."""
 
-    def __init__(self, index: "DeviceIndex", max_queries: int, max_terms: int, k: int, depth: int = 2, validate: bool = True):
+    def __init__(self, index: "DeviceIndex", max_queries: int, max_terms: int, k: int, depth: int = 3, validate: bool = True,
+                 zero_copy_queries: bool = True):
         torch = _torch()
         if not (1 <= k <= _capi.limits()["max_k"]):
             raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
         self.index, self.k, self.depth, self.validate = index, int(k), int(depth), validate
+        self.zero_copy = bool(zero_copy_queries)
         self.max_queries, self.max_terms = int(max_queries), int(max_terms)
         dev = index.device
         qwords = self.max_queries + 1 + 2 * self.max_terms
         row = 2 * self.k + 1
+        ws_bytes = max(index.workspace_bytes(self.max_queries, self.k), 1 << 20)
         self.slots = []
         with torch.cuda.device(dev):
-            self.s_in, self.s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             for _ in range(self.depth):
                 self.slots.append({
+                    "stream": torch.cuda.Stream(device=dev),
                     "h_q": torch.empty(qwords, dtype=torch.int32).pin_memory(), "d_q": torch.empty(qwords, dtype=torch.int32, device=dev),
                     "d_out": torch.empty((self.max_queries, row), dtype=torch.int32, device=dev),
                     "h_out": torch.empty((self.max_queries, row), dtype=torch.int32).pin_memory(),
-                    "ev_in": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "ev_out": torch.cuda.Event(), "busy": False, "nq": 0})
+                    "ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "busy": False, "nq": 0})
+            torch.cuda.synchronize(dev)  # the buffers exist before any slot stream touches them
         self._n = 0
 
     def submit(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> int:
         torch = _torch()
+        L = _capi.lib()
         nq, nt = len(q_ptr) - 1, int(q_ptr[-1])
         if nq > self.max_queries or nt > self.max_terms:
             raise ValueError("batch larger than the pipeline was sized for")
@@ -543,23 +553,18 @@ class HostBatchPipeline:
         hq[: nq + 1] = q_ptr
         hq[nq + 1: nq + 1 + nt] = q_term[:nt]
         hq[nq + 1 + nt: nq + 1 + 2 * nt].view(np.float32)[:] = q_weight[:nt]
-        dev = self.index.device
-        main = torch.cuda.current_stream(dev)
         n_words = nq + 1 + 2 * nt
-        with torch.cuda.stream(self.s_in):
-            s["d_q"][:n_words].copy_(s["h_q"][:n_words], non_blocking=True)
-            s["ev_in"].record(self.s_in)
-        main.wait_event(s["ev_in"])
-        dq = s["d_q"]
+        st = s["stream"]
+        if self.zero_copy:
+            dq = s["h_q"]  # pinned host memory is mapped into the device's address space: the kernels read it in place
+        else:
+            _capi.check(L.srx_memcpy_async(s["d_q"].data_ptr(), s["h_q"].data_ptr(), 4 * n_words, st.cuda_stream), "srx_memcpy_async")
+            dq = s["d_q"]
         if nq:
             self.index.search_packed_device(dq[: nq + 1], dq[nq + 1: nq + 1 + nt], dq[nq + 1 + nt: n_words].view(torch.float32),
-                                            self.k, out=s["d_out"][:nq])
-        s["ev_done"].record(main)
-        with torch.cuda.stream(self.s_out):
-            self.s_out.wait_event(s["ev_done"])
-            if nq:
-                s["h_out"][:nq].copy_(s["d_out"][:nq], non_blocking=True)
-            s["ev_out"].record(self.s_out)
+                                            self.k, out=s["d_out"][:nq], stream=st, workspace=s["ws"])
+            _capi.check(L.srx_memcpy_async(s["h_out"].data_ptr(), s["d_out"].data_ptr(), 4 * nq * (2 * self.k + 1), st.cuda_stream),
+                        "srx_memcpy_async")
         s["busy"], s["nq"] = True, nq
         self._n += 1
         return ticket
@@ -569,7 +574,7 @@ class HostBatchPipeline:
         s = self.slots[ticket % self.depth]
         if not s["busy"] or ticket < self._n - self.depth:
             raise RuntimeError("ticket already consumed or overwritten")
-        s["ev_out"].synchronize()
+        s["stream"].synchronize()
         s["busy"] = False
         rows = s["h_out"].numpy()[: s["nq"]]
         k = self.k

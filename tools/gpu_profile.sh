@@ -10,7 +10,7 @@ ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $@"
 # the kernel-trace pass runs the bench's own default protocol (3 warm-up + 20 timed steps), so that its per-launch
 # durations are comparable with the hipEvent figure of a default run (the first launches of a process are slower:
 # clocks ramp up)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $@ > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps ${TRACE_STEPS:-20} --warmup 3 --no-cpu-baseline $@ > $out/trace.log 2>&1
 echo "trace rc=$?" >> $out/summary.txt
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
