@@ -77,6 +77,16 @@ SYMBOLS = {
 _lib: Optional[ctypes.CDLL] = None
 
 
+def kernel_sources_sha256() -> str:
+    """sha256 over the kernel sources (csrc/*.hip + srx_common.h): identifies the build a profile was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + ["srx_common.h"]:
+        with open(os.path.join(CSRC_DIR, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _deps():
     return [os.path.join(CSRC_DIR, f) for f in SOURCES] + [os.path.join(CSRC_DIR, "srx_common.h"),
                                                             os.path.join(INCLUDE_DIR, "sparse_rx.h")]

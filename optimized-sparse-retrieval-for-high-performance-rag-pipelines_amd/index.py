@@ -499,19 +499,20 @@ class DeviceIndex:
 
 
 class HostBatchPipeline:
-    """Host batches in, host rows out, with the PCIe copies off the critical path (the metric's batch
+    """Host batches in, host rows out, with the PCIe traffic off the critical path (the metric's batch
     wall time includes the H2D of the query batch and the D2H of the nq x k results).
 
-    ``depth`` slots (3 = triple buffering), each with its own HIP stream, pinned host staging for the query CSR
-    (q_ptr | q_term | q_weight packed into one int32 block), a device block of packed result rows
-    [k doc ids][k score bits][count] written directly by ``srx_search_packed``, a pinned host block for them and its own
-    search workspace.  A batch's work -- (H2D of the query block,) search, ONE D2H copy of the rows -- is submitted to
-    its slot's stream in order, so nothing has to be ordered across streams (no events: an event record / wait pair
-    costs ~0.15 ms of host time on this stack, a stream-guarded tensor copy ~1 ms), while batches of different slots
-    overlap on the GPU: batch i+1 is scored while batch i's rows travel to the host.  By default the kernels read the
-    query block straight from the pinned (device-mapped) staging buffer (``zero_copy_queries``): a few hundred KB
-    touched once, no copy call at all.  ``submit`` returns a ticket at once; ``result(ticket)`` waits for that slot's
-    stream and returns NumPy views of the pinned rows (valid until the slot is reused ``depth`` submits later)."""
+    ``depth`` slots (3 = triple buffering), each with pinned host staging for the query CSR (q_ptr | q_term | q_weight
+    packed into one int32 block), a device block of packed result rows [k doc ids][k score bits][count] written
+    directly by ``srx_search_packed`` and a pinned host block for them.  The searches run back to back on the caller's
+    current stream; each batch's rows go to the host with ONE ``hipMemcpyAsync`` (``srx_memcpy_async``) on a copy stream
+    ordered behind its search by an event, so batch i+1 is scored while batch i's rows travel.  By default the kernels
+    read the query block straight from the pinned (device-mapped) staging buffer (``zero_copy_queries``): a few hundred
+    KB touched once, no copy call at all.  (Measured on this stack, tools/copy_issue_probe.py: a stream-guarded
+    ``Tensor.copy_`` costs ~1 ms of host time per call, launching the search on a side stream ~0.8 ms, a C-ABI async
+    copy ~0.1 ms, an event record a few microseconds.)  ``submit`` returns a ticket at once; ``result(ticket)`` waits
+    for that batch's copy and returns NumPy views of the pinned rows (valid until the slot is reused ``depth`` submits
+    later)."""
 
     def __init__(self, index: "DeviceIndex", max_queries: int, max_terms: int, k: int, depth: int = 3, validate: bool = True,
                  zero_copy_queries: bool = True):
@@ -524,17 +525,16 @@ class HostBatchPipeline:
         dev = index.device
         qwords = self.max_queries + 1 + 2 * self.max_terms
         row = 2 * self.k + 1
-        ws_bytes = max(index.workspace_bytes(self.max_queries, self.k), 1 << 20)
         self.slots = []
         with torch.cuda.device(dev):
+            self.s_copy = torch.cuda.Stream(device=dev)
             for _ in range(self.depth):
                 self.slots.append({
-                    "stream": torch.cuda.Stream(device=dev),
                     "h_q": torch.empty(qwords, dtype=torch.int32).pin_memory(), "d_q": torch.empty(qwords, dtype=torch.int32, device=dev),
                     "d_out": torch.empty((self.max_queries, row), dtype=torch.int32, device=dev),
                     "h_out": torch.empty((self.max_queries, row), dtype=torch.int32).pin_memory(),
-                    "ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "busy": False, "nq": 0})
-            torch.cuda.synchronize(dev)  # the buffers exist before any slot stream touches them
+                    "ev_done": torch.cuda.Event(), "ev_out": torch.cuda.Event(), "busy": False, "nq": 0})
+            torch.cuda.synchronize(dev)
         self._n = 0
 
     def submit(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> int:
@@ -554,17 +554,21 @@ class HostBatchPipeline:
         hq[nq + 1: nq + 1 + nt] = q_term[:nt]
         hq[nq + 1 + nt: nq + 1 + 2 * nt].view(np.float32)[:] = q_weight[:nt]
         n_words = nq + 1 + 2 * nt
-        st = s["stream"]
+        main = torch.cuda.current_stream(self.index.device)
         if self.zero_copy:
             dq = s["h_q"]  # pinned host memory is mapped into the device's address space: the kernels read it in place
         else:
-            _capi.check(L.srx_memcpy_async(s["d_q"].data_ptr(), s["h_q"].data_ptr(), 4 * n_words, st.cuda_stream), "srx_memcpy_async")
+            _capi.check(L.srx_memcpy_async(s["d_q"].data_ptr(), s["h_q"].data_ptr(), 4 * n_words, main.cuda_stream), "srx_memcpy_async")
             dq = s["d_q"]
         if nq:
             self.index.search_packed_device(dq[: nq + 1], dq[nq + 1: nq + 1 + nt], dq[nq + 1 + nt: n_words].view(torch.float32),
-                                            self.k, out=s["d_out"][:nq], stream=st, workspace=s["ws"])
-            _capi.check(L.srx_memcpy_async(s["h_out"].data_ptr(), s["d_out"].data_ptr(), 4 * nq * (2 * self.k + 1), st.cuda_stream),
-                        "srx_memcpy_async")
+                                            self.k, out=s["d_out"][:nq])
+        s["ev_done"].record(main)
+        self.s_copy.wait_event(s["ev_done"])
+        if nq:
+            _capi.check(L.srx_memcpy_async(s["h_out"].data_ptr(), s["d_out"].data_ptr(), 4 * nq * (2 * self.k + 1),
+                                           self.s_copy.cuda_stream), "srx_memcpy_async")
+        s["ev_out"].record(self.s_copy)
         s["busy"], s["nq"] = True, nq
         self._n += 1
         return ticket
@@ -574,7 +578,7 @@ class HostBatchPipeline:
         s = self.slots[ticket % self.depth]
         if not s["busy"] or ticket < self._n - self.depth:
             raise RuntimeError("ticket already consumed or overwritten")
-        s["stream"].synchronize()
+        s["ev_out"].synchronize()
         s["busy"] = False
         rows = s["h_out"].numpy()[: s["nq"]]
         k = self.k

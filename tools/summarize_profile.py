@@ -12,7 +12,8 @@ tag, name = sys.argv[1], sys.argv[2]
 wkey = sys.argv[3] if len(sys.argv) > 3 else "c3@1"
 dom = sys.argv[4] if len(sys.argv) > 4 else "srx_wave_kernel"
 out = f"gpurun_out/prof_{tag}"
-SRC = "optimized-sparse-retrieval-for-high-performance-rag-pipelines_amd/csrc/sparse_rx.hip"
+sys.path.insert(0, ".")
+import sparse_rx  # noqa: E402  (only for the source hash; no GPU needed)
 
 
 def short(kn):
@@ -52,8 +53,8 @@ for f in sorted(glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=T
 w = pm[dom]
 hbm = (2 * w.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024
 lines.append(f"derived {dom} hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {hbm:.6g}")
-sha = hashlib.sha256(open(SRC, "rb").read()).hexdigest()
-lines.append(f"kernel source sha256 ({SRC}) = {sha}")
+sha = sparse_rx._capi.kernel_sources_sha256()
+lines.append(f"kernel sources sha256 (csrc/*.hip + srx_common.h) = {sha}")
 args = open(out + "/args.txt").read().strip() if os.path.exists(out + "/args.txt") else ""
 open(f"profiles/{name}_rocprofv3_summary.txt", "w").write(
     f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline {args} (3 warm-up + 20 timed "
