@@ -230,12 +230,16 @@ int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpu
 
 /* Dense f32 side: replaces np.dot(embedding_index, query_vector) + the top-k after it in
  * RetrievalService.search_by_vector (rag_system/core/retrieval.py:411-423).  emb f32[n_docs][dim], queries f32[nq][dim],
- * dim a multiple of 64, <= 1024 (pad with zeros).  Results: the k largest scores > 0 per query, ranked (score desc,
- * doc asc).  The summation order of the reference's BLAS matvec is unspecified: scores agree to ~1e-6 relative. */
+ * dim a multiple of 64, <= 1024 (pad with zeros).  Results: the k largest values of (score + score_offset) > 0 per query,
+ * ranked (desc, doc asc), returned WITH the offset.  score_offset = 0 gives the positive scores themselves; an offset
+ * above the largest |score| makes every doc rankable, which is how the host side serves search_by_vector's
+ * min_score <= 0 (the reference returns zero / negative scores down to min_score, retrieval.py:425-436) -- it then
+ * re-evaluates the k returned rows' scores itself.  The summation order of the reference's BLAS matvec is unspecified:
+ * scores agree to ~1e-6 relative. */
 int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k);
 int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
                          int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
-                         void *workspace, int64_t workspace_bytes, void *stream);
+                         void *workspace, int64_t workspace_bytes, void *stream, float score_offset);
 
 /* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = tier-1
  * wave kernel, h_ms[1] = tier-2 block kernel, h_ms[2] = merge kernel, h_ms[3] = whole call (milliseconds,

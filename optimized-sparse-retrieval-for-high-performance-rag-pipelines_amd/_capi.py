@@ -65,7 +65,7 @@ SYMBOLS = {
     "srx_dense_workspace_bytes": (_I64, [_I32, _I64, _I32]),
     "srx_dense_search_i8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_dense_f32_workspace_bytes": (_I64, [_I32, _I64, _I32]),
-    "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP, ctypes.c_float]),
     "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
     "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "srx_memcpy_async": (ctypes.c_int, [_VP, _VP, _I64, _VP]),
@@ -78,10 +78,11 @@ _lib: Optional[ctypes.CDLL] = None
 
 
 def kernel_sources_sha256() -> str:
-    """sha256 over the kernel sources (csrc/*.hip + srx_common.h): identifies the build a profile was taken from."""
+    """sha256 over the sparse path's kernel sources (wave_kernel.hip, sparse_rx.hip, srx_common.h): identifies the build a
+    profile was taken from."""
     import hashlib
     h = hashlib.sha256()
-    for f in SOURCES + ["srx_common.h"]:
+    for f in ["wave_kernel.hip", "sparse_rx.hip", "srx_common.h"]:
         with open(os.path.join(CSRC_DIR, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -431,7 +431,7 @@ constexpr int F32_MAXS = 16; // dim <= 1024 = 16 slices of 64
 
 __global__ __launch_bounds__(THREADS) void srx_dense_f32_scores_kernel(const float *__restrict__ emb, int64_t n_docs, int dim,
                                                                        const float *__restrict__ queries, int nqp,
-                                                                       float *__restrict__ scores, int64_t ld) {
+                                                                       float *__restrict__ scores, int64_t ld, float score_offset) {
     const int lane = threadIdx.x & 63;
     const int ns = dim >> 6;  // slices of 64 columns (dim is a multiple of 64)
     float qv[F32_QP][F32_MAXS];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_f32_scores_kernel(const flo
                 for (int i = 0; i < F32_MAXS; ++i) a = a + r[i] * qv[q][i];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o);
-                if (lane == 0) scores[(int64_t)q * ld + d] = a;
+                if (lane == 0) scores[(int64_t)q * ld + d] = a + score_offset;  // + 0.0f by default (exact)
             }
         }
     }
@@ -469,7 +469,7 @@ SRX_API int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_
 
 SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
                                  int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
-                                 void *workspace, int64_t workspace_bytes, void *stream_v) {
+                                 void *workspace, int64_t workspace_bytes, void *stream_v, float score_offset) {
     if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: need n_docs > 0, 1 <= k <= 1024%s");
     if (dim <= 0 || dim % 64 != 0 || dim > 64 * F32_MAXS)
         return fail(SRX_ERR_INVALID, "srx_dense_search_f32: dim must be a multiple of 64, <= 1024 (pad the rows with zeros)%s");
@@ -491,7 +491,7 @@ SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_doc
     for (int q0 = 0; q0 < nq; q0 += F32_QP) {
         const int qb = nq - q0 < F32_QP ? nq - q0 : F32_QP;
         hipLaunchKernelGGL(srx_dense_f32_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, emb, n_docs, (int)dim,
-                           queries + (int64_t)q0 * dim, qb, scores, ld);
+                           queries + (int64_t)q0 * dim, qb, scores, ld, score_offset);
         hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb, k,
                            ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0,
                            (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr);
@@ -503,14 +503,3 @@ SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_doc
     }
     return SRX_OK;
 }
-
-#ifdef SRX_STAMP
-// Diagnostic build only: cumulative s_memtime ticks per kernel segment (see STAMP in srx_wave_kernel); resets.
-extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16));
-    unsigned long long z[16] = {0};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
-    return 0;
-}
-#endif

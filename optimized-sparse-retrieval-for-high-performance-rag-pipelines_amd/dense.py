@@ -145,7 +145,8 @@ class DenseF32Index:
         self.doc_base = int(doc_base)
         self._ws = None
 
-    def search_device(self, queries, k: int):
+    def search_device(self, queries, k: int, score_offset: float = 0.0):
+        """Top-k of (score + score_offset) > 0 per query (include/sparse_rx.h); the returned scores carry the offset."""
         torch = _torch()
         if not (1 <= k <= _capi.limits()["max_k"]):
             raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
@@ -163,15 +164,15 @@ class DenseF32Index:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             rc = L.srx_dense_search_f32(self.device.index or 0, _ptr(self.emb), self.n_docs, self.dim_pad, _ptr(q), nq, k, self.doc_base,
                                         _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(self._ws), self._ws.numel(),
-                                        _stream_ptr(torch, self.device))
+                                        _stream_ptr(torch, self.device), float(score_offset))
             _capi.check(rc, "srx_dense_search_f32")
         return out
 
-    def search(self, queries: np.ndarray, k: int):
+    def search(self, queries: np.ndarray, k: int, score_offset: float = 0.0):
         torch = _torch()
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
-        d, s, n = self.search_device(torch.as_tensor(q, device=self.device), k)
+        d, s, n = self.search_device(torch.as_tensor(q, device=self.device), k, score_offset)
         torch.cuda.synchronize(self.device)
         return d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()

@@ -93,7 +93,12 @@ class _SparseRetrieverBase:
             pending[key].append(qid)
         if texts:
             q_ptr, q_term, q_w = encode_queries(texts, self.host.vocabulary, order=self.term_order)
-            docs, scores, counts = self.dev.search(q_ptr, q_term, q_w, min(int(top_k), self.host.n_docs))
+            k_eff = min(int(top_k), self.host.n_docs)
+            from . import _capi
+            if not (1 <= k_eff <= _capi.limits()["max_k"]):
+                raise ValueError(f"top_k = {top_k} on a corpus of {self.host.n_docs} docs: the HIP engine ranks between 1 and "
+                                 f"{_capi.limits()['max_k']} results per query")
+            docs, scores, counts = self.dev.search(q_ptr, q_term, q_w, k_eff)
             for i, key in enumerate(keys):
                 if q_ptr[i + 1] == q_ptr[i]:
                     continue

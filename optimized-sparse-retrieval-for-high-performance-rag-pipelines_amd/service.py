@@ -3,8 +3,11 @@
 
 Same names, argument meaning, result shape and error behaviour for the hot path:
 ``build_bm25_index(corpus)`` (:129), ``search_bm25(queries, top_k)`` (:203), ``get_stats()`` (:471),
-``clear_cache()`` (:464), ``close()`` / context manager (:495-506).  The document store (MemoryIndex) and the
-dense ``search_by_vector`` side are outside this build's scope.
+``clear_cache()`` (:464), ``close()`` / context manager (:495-506), and the dense ``search_by_vector`` (:402-436).  The
+document store (MemoryIndex) is outside this build's scope.
+
+``top_k``: after clamping to the corpus size it must be <= 1024 (the engine's list capacity; ``ValueError`` otherwise --
+the reference accepts any value); ``top_k <= 0`` returns ``{}`` for every query like the reference's ``argpartition``.
 
 What changes underneath: ``search_bm25`` scores the WHOLE query dict as one batch through
 ``srx_search`` (libsparse_rx.so) instead of looping ``simd_bm25_score`` + ``fast_topk_selection`` per query
@@ -104,6 +107,12 @@ class RetrievalService:
         """retrieval.py:203-231 semantics; one batched GPU call for all uncached queries."""
         if self.host is None:
             raise ValueError("BM25 index not built. Call build_bm25_index() first.")  # :205-206
+        k_eff = min(int(top_k), self.host.n_docs)  # k >= n_docs -> everything, ranked (:281-284)
+        if k_eff > _capi.limits()["max_k"]:
+            raise ValueError(f"top_k = {top_k} on a corpus of {self.host.n_docs} docs: the HIP engine ranks at most "
+                             f"{_capi.limits()['max_k']} results per query (the reference accepts any top_k)")
+        if k_eff <= 0:  # the reference's argpartition(-scores, 0)[:0] keeps nothing (:276-279)
+            return {qid: {} for qid in queries}
         if (self.k1, self.b) != self._built_k1b:
             self._upload()  # k1 / b are plain attributes on the reference (:116-117): impacts depend on them
         results: Dict[str, Dict[str, float]] = {}
@@ -128,7 +137,6 @@ class RetrievalService:
             pending[key].append(qid)
         if texts:
             q_ptr, q_term, q_weight = encode_queries(texts, self.host.vocabulary)
-            k_eff = min(int(top_k), self.host.n_docs)  # k >= n_docs -> everything, ranked (:281-284)
             docs, scores, counts = self.dev.search(q_ptr, q_term, q_weight, k_eff)
             for i, key in enumerate(keys):
                 if q_ptr[i + 1] == q_ptr[i]:  # no token / no in-vocabulary term -> {} and nothing cached (:237-238, :251-252)
@@ -159,28 +167,45 @@ class RetrievalService:
         if e.ndim != 2 or (self.doc_ids and e.shape[0] != len(self.doc_ids)):
             raise ValueError("embeddings must be [n_docs, dim] with one row per document")
         self.embedding_index = e
+        self._emb_absmax = float(np.abs(e).max()) if e.size else 0.0
         self._dense = DenseF32Index(e, device=self.device)
 
     def search_by_vector(self, query_vector: np.ndarray, k: int = 10, min_score: float = 0.0) -> List[Dict]:
         """retrieval.py:402-436: ``np.dot(embedding_index, query_vector)`` + top-k on the GPU (``srx_dense_search_f32``),
-        the ``min_score`` cut and the ``[{"doc_id", "score"}]`` result as in the reference.  (The engine only returns
-        scores > 0, so ``min_score`` < 0 does not bring negative scores back.)"""
+        the ``min_score`` cut and the ``[{"doc_id", "score"}]`` result as in the reference.
+
+        The engine ranks positive values only.  For ``min_score > 0`` that is all the reference can return either.  For
+        ``min_score <= 0`` (the default is 0.0: rows with a score of exactly 0 count, and negative thresholds admit
+        negative scores, :425-427) the scores are shifted by a bound on the largest |score| so that every doc is
+        rankable; the k returned rows are then re-scored on the host with ``np.dot`` (fp32, the reference's own
+        expression) and re-ranked, so the shift never shows in the result."""
         if getattr(self, "_dense", None) is None and self.embedding_path and os.path.exists(str(self.embedding_path)) and self.doc_ids:
             n = len(self.doc_ids)
             dim = os.path.getsize(str(self.embedding_path)) // (n * 4)  # retrieval.py:324-328
             self.set_embeddings(np.memmap(str(self.embedding_path), dtype="float32", mode="r", shape=(n, dim)))
         if getattr(self, "_dense", None) is None:
             raise ValueError("No embedding index available")
+        q = np.asarray(query_vector, dtype=np.float32)
         kk = max(1, min(int(k), self._dense.n_docs))
-        d, s, n = self._dense.search(np.asarray(query_vector, dtype=np.float32), kk)
+        if min_score > 0:
+            d, s, n = self._dense.search(q, kk)
+            idx, sc = d[0, : int(n[0])].astype(np.int64), s[0, : int(n[0])]
+        else:
+            bound = float(np.abs(q).sum(dtype=np.float64)) * self._emb_absmax  # >= |score| of every doc
+            offset = 2.0 * bound + abs(float(min_score)) + 1.0
+            d, s, n = self._dense.search(q, kk, score_offset=offset)
+            idx = d[0, : int(n[0])].astype(np.int64)
+            sc = np.dot(self.embedding_index[idx], q).astype(np.float32)  # the reference's fp32 expression on the k rows
+            order = np.argsort(-sc, kind="stable")
+            idx, sc = idx[order], sc[order]
         results = []
-        for idx, score in zip(d[0, : int(n[0])], s[0, : int(n[0])]):
+        for i, score in zip(idx, sc):
             if score < min_score:
                 break
-            if self.doc_ids and idx < len(self.doc_ids):
-                results.append({"doc_id": self.doc_ids[int(idx)], "score": float(score)})
+            if self.doc_ids and i < len(self.doc_ids):
+                results.append({"doc_id": self.doc_ids[int(i)], "score": float(score)})
             elif not self.doc_ids:
-                results.append({"doc_id": str(int(idx)), "score": float(score)})
+                results.append({"doc_id": str(int(i)), "score": float(score)})
         return results
 
     def clear_cache(self) -> None:

@@ -167,9 +167,11 @@ def test_service_search_by_vector(tmp_path):
     rng = np.random.default_rng(3)
     corpus = {f"d{i}": {"text": f"word{i} common"} for i in range(50)}
     emb = rng.standard_normal((50, 96)).astype(np.float32)
+    emb[7] = 0.0  # a score of exactly 0: returned under the default min_score = 0.0 (retrieval.py:425-427), after the positives
     qv = rng.standard_normal(96).astype(np.float32)
     exp = np.dot(emb, qv)
     order = [i for i in np.argsort(-exp) if exp[i] > 0][:10]
+    n_pos = int((exp > 0).sum())
     svc = sparse_rx.RetrievalService()
     svc.build_bm25_index(corpus)
     with pytest.raises(ValueError, match="No embedding index available"):
@@ -179,6 +181,17 @@ def test_service_search_by_vector(tmp_path):
     assert [r["doc_id"] for r in got] == [f"d{i}" for i in order]
     assert np.allclose([r["score"] for r in got], exp[order], rtol=1e-5, atol=1e-6)
     assert len(svc.search_by_vector(qv, k=10, min_score=float(exp[order[3]]) - 1e-6)) == 4
+    # min_score <= 0: zero and negative scores come back too, down to the threshold, in the reference's order
+    full = [int(i) for i in np.argsort(-exp, kind="stable")]
+    got0 = svc.search_by_vector(qv, k=50)  # default min_score = 0.0
+    assert [r["doc_id"] for r in got0] == [f"d{i}" for i in full[: n_pos + 1]] and got0[-1] == {"doc_id": "d7", "score": 0.0}
+    gotn = svc.search_by_vector(qv, k=50, min_score=-1e9)
+    assert [r["doc_id"] for r in gotn] == [f"d{i}" for i in full]
+    assert np.allclose([r["score"] for r in gotn], exp[full], rtol=1e-5, atol=1e-6)
+    thr = float(exp[full[n_pos + 5]])
+    gott = svc.search_by_vector(qv, k=50, min_score=thr - 1e-6)
+    assert [r["doc_id"] for r in gott] == [f"d{i}" for i in full[: n_pos + 6]]
+    assert [r["doc_id"] for r in svc.search_by_vector(qv, k=3, min_score=-1e9)] == [f"d{i}" for i in full[:3]]
     p = tmp_path / "emb.bin"
     emb.tofile(p)
     svc2 = sparse_rx.RetrievalService(embedding_path=str(p))

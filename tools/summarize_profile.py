@@ -23,8 +23,18 @@ def short(kn):
     return None
 
 
+def newest_per_dir(pattern):
+    """gpurun merges every call's files into the same local directory: keep the newest file of each PMC pass."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = f.split("/")[2]
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 lines = []
-for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+for f in newest_per_dir(out + "/trace/**/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{name}_kernel_stats.csv")
     for row in csv.DictReader(open(f)):
         n = short(row["Name"])
@@ -32,14 +42,14 @@ for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
             lines.append(f"kernel_stats {n:18s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f} "
                          f"min_ns={row['MinNs']} max_ns={row['MaxNs']} pct={row['Percentage']}")
 # per-launch durations of the dominant kernel in dispatch order: 3 warm-up, 20 timed, then the PCIe-inclusive launches
-for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+for f in newest_per_dir(out + "/trace/**/*kernel_trace.csv"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if dom in r["Kernel_Name"]]
     if len(d) >= 23:
         timed = d[3:23]
         lines.append(f"kernel_trace {dom} per launch (ms), dispatch order: " + " ".join(f"{x:.3f}" for x in d))
         lines.append(f"kernel_trace {dom} timed launches 4..23: avg_ms={sum(timed) / len(timed):.4f} min_ms={min(timed):.4f} max_ms={max(timed):.4f}")
 pm = collections.defaultdict(dict)
-for f in sorted(glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True)):
+for f in newest_per_dir(out + "/pmc_*/**/*counter_collection.csv"):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
         kn = short(row.get("Kernel_Name", ""))
