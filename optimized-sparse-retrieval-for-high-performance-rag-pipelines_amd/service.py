@@ -167,7 +167,7 @@ class RetrievalService:
         if e.ndim != 2 or (self.doc_ids and e.shape[0] != len(self.doc_ids)):
             raise ValueError("embeddings must be [n_docs, dim] with one row per document")
         self.embedding_index = e
-        self._emb_absmax = float(np.abs(e).max()) if e.size else 0.0
+        self._emb_maxnorm = float(np.sqrt((e.astype(np.float64) ** 2).sum(axis=1).max())) if e.size else 0.0
         self._dense = DenseF32Index(e, device=self.device)
 
     def search_by_vector(self, query_vector: np.ndarray, k: int = 10, min_score: float = 0.0) -> List[Dict]:
@@ -191,8 +191,10 @@ class RetrievalService:
             d, s, n = self._dense.search(q, kk)
             idx, sc = d[0, : int(n[0])].astype(np.int64), s[0, : int(n[0])]
         else:
-            bound = float(np.abs(q).sum(dtype=np.float64)) * self._emb_absmax  # >= |score| of every doc
-            offset = 2.0 * bound + abs(float(min_score)) + 1.0
+            # |score| <= |q|_2 * max row norm (Cauchy-Schwarz): the smallest shift that makes every doc rankable keeps
+            # the most fp32 resolution for the ranking (the shifted scores are only used to pick the k rows)
+            bound = float(np.linalg.norm(q.astype(np.float64))) * self._emb_maxnorm
+            offset = bound * 1.001 + 1e-30
             d, s, n = self._dense.search(q, kk, score_offset=offset)
             idx = d[0, : int(n[0])].astype(np.int64)
             sc = np.dot(self.embedding_index[idx], q).astype(np.float32)  # the reference's fp32 expression on the k rows
