@@ -83,7 +83,7 @@ WORKLOADS = {
     "c1": dict(n_docs=57_638, vocab=80_000, nnz_per_doc=130, n_queries=100, terms=10, k=10, seed=20251, kind="text"),
     # secondary workloads (BASELINE.json configs[3], configs[4]); single-GPU numbers are reported in DESIGN.md only
     "c4": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20254,
-               kind="splade"),
+               kind="splade", tile_log2=12),  # 4096-doc tiles: tier 2's wave-level dense path (four tiles per workgroup)
     # dev variant of c4 without hot terms (uniform term ids): every tile holds ~4 k postings of ~50 terms
     "c4u": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20256,
                 kind="splade", zipf_s=0.0),
@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--docs", type=int, default=0, help="override n_docs (scaled-down checks; marks the workload custom)")
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
-    ap.add_argument("--tile-log2", type=int, default=14)
+    ap.add_argument("--tile-log2", type=int, default=0, help="docs per skip-table tile = 2^n (0 = the workload's default, 14 unless it says otherwise)")
     ap.add_argument("--supertile-log2", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     ap.add_argument("--unit-tiles", type=int, default=0)
@@ -196,6 +196,8 @@ def main():
             w[key] = val
             custom = True
     kind = w.get("kind", "uniform")
+    if args.tile_log2 == 0:
+        args.tile_log2 = w.get("tile_log2", 14)
     n_docs, V, k, nq = w["n_docs"], w["vocab"], w["k"], w["n_queries"]
     want_check = not args.no_cpu_baseline          # oracle checks (and, at N = 1, the timed CPU baseline)
     want_cpu = want_check and world == 1 and not args.force_dist

@@ -178,10 +178,12 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
         return i;
     };
     auto span_of = [&](int i) { return (int)(S.m_start[i] & 3) + S.m_len[i]; };  // postings from the first block's start
-    auto load_batch = [&](int i, int o, int (&d)[NB], float (&v)[NB]) {
+    auto load_batch = [&](int i_, int o, int (&d)[NB], float (&v)[NB]) {
+        const bool valid = i_ < nt;        // past the last batch: the loads are still issued (a constant number in flight ->
+        const int i = valid ? i_ : 0;      // counted vmcnt waits), everything masked
         const int64_t start = S.m_start[i];
         const int head = (int)(start & 3);
-        const int span = head + S.m_len[i];
+        const int span = valid ? head + S.m_len[i] : 0;
         const int64_t b0 = start >> 2;
 #pragma unroll
         for (int h = 0; h < NB / 4; ++h) {
@@ -202,18 +204,23 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
         // The postings of one batch belong to one term, so their docs are distinct: read all accumulators, then write
         // them all (written as one loop of read-modify-writes the compiler has to assume the addresses may alias and
         // serialises NB LDS round trips per batch -- the dense tiles' main stall before).
+        // Branch-free: a masked posting (doc < 0) reads and writes a private dummy word instead of an accumulator (as
+        // per-posting branches the compiler emitted one exec-masked block and one LDS wait per posting).
+        float *const dummy = reinterpret_cast<float *>(S.st_off) + (tid & 63);  // the hash path's step table is idle here
+        float *slot[NB];
         float acc_r[NB];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) acc_r[r] = (d[r] >= 0) ? acc[d[r] - tile_base] : 0.0f;
+        for (int r = 0; r < NB; ++r) slot[r] = (d[r] >= 0) ? acc + (d[r] - tile_base) : dummy;
 #pragma unroll
-        for (int r = 0; r < NB; ++r)
-            if (d[r] >= 0) acc[d[r] - tile_base] = acc_r[r] + (v[r] * idf) * qw;
+        for (int r = 0; r < NB; ++r) acc_r[r] = *slot[r];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) *slot[r] = acc_r[r] + (v[r] * idf) * qw;
     };
     // K batches in flight: register set j holds batch n with n % K == j; after batch n has been accumulated its set is
     // refilled with batch n + K.  (One batch ahead left a many-term tile -- 50 terms of < 1 batch each -- paying one full
     // memory round trip per term: profiles/r02_c4_*.)
 #ifndef SRX_DENSE_DEPTH
-#define SRX_DENSE_DEPTH 2
+#define SRX_DENSE_DEPTH 4
 #endif
     constexpr int K = SRX_DENSE_DEPTH;
     int qi[K], qo[K];  // term / offset of the batch in set j (qi == nt: none)
@@ -232,30 +239,19 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
     for (int j = 0; j < K; ++j) {
         qi[j] = ni;
         qo[j] = no;
-        if (ni < nt) {
-            load_batch(ni, no, dq[j], vq[j]);
-            advance();
-        }
+        load_batch(ni, no, dq[j], vq[j]);
+        if (ni < nt) advance();
     }
-    bool more = true;
-    while (more) {
+    while (qi[0] < nt) {  // set 0 holds the oldest batch at the top of the loop
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (more) {
-                if (qi[j] >= nt) {
-                    more = false;
-                } else {
-                    add_batch(qi[j], dq[j], vq[j]);
-                    const int nxt = qi[(j + 1) % K];  // term of the batch that is accumulated next
-                    if (nxt < nt && nxt != qi[j]) __syncthreads();  // next term: order the adds per doc
-                    qi[j] = ni;
-                    qo[j] = no;
-                    if (ni < nt) {
-                        load_batch(ni, no, dq[j], vq[j]);
-                        advance();
-                    }
-                }
-            }
+            if (qi[j] < nt) add_batch(qi[j], dq[j], vq[j]);  // uniform
+            const int nxt = qi[(j + 1) % K];  // term of the batch that is accumulated next
+            if (qi[j] < nt && nxt < nt && nxt != qi[j]) __syncthreads();  // next term: order the adds per doc
+            qi[j] = ni;
+            qo[j] = no;
+            load_batch(ni, no, dq[j], vq[j]);
+            if (ni < nt) advance();
         }
     }
     __syncthreads();
@@ -443,6 +439,101 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
     return true;
 }
 
+// Dense accumulation of ONE tile by ONE wavefront (tiles of <= 4096 docs: four waves' accumulators fit the 64 KiB table,
+// so a workgroup takes four consecutive tiles at a time).  No block barrier anywhere: the wave streams the tile's runs
+// term by term in the query's term order and one wave's LDS instructions execute in order, which is all the per-doc
+// summation order needs.  Lane i < nt carries term i's run in this tile (wstart / wlen); the loads of the next blocks
+// (across term boundaries) are in flight while a block is accumulated.  The block kernel's term-by-term form costs a
+// barrier and a memory round trip per term: on 50-term learned-sparse queries (C4) that was 85 % of its time.
+template <typename VT>
+__device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int nt, int64_t tile_base, bool has_tile, int64_t wstart,
+                                      int wlen) {
+    constexpr int BW = BlockWords<VT>::value;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = 1 << ix.tile_log2;
+    float *acc = reinterpret_cast<float *>(S.tbl) + wave * G;
+    for (int i = lane; i < G / 4; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!has_tile) return;  // uniform per wave
+    const int32_t *post = ix.post;
+    // iterator over (term, step): 64 blocks per step
+    int it = 0, istep = 0;       // next (term, step) to load
+    int64_t cs = 0;              // its run start / length (uniform)
+    int cl = 0, cnb = 0;
+    auto seek = [&]() {          // make (it, istep) point at an existing step, or it = nt
+        for (;;) {
+            if (it >= nt) return;
+            if (istep == 0) {
+                cs = ((int64_t)__builtin_amdgcn_readlane((int)(wstart >> 32), it) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)(wstart & 0xFFFFFFFFll), it);
+                cl = __builtin_amdgcn_readlane(wlen, it);
+                cnb = cl > 0 ? (int)(((cs & 3) + cl + 3) >> 2) : 0;
+            }
+            if (istep * 64 < cnb) return;
+            ++it;
+            istep = 0;
+        }
+    };
+    struct Blk {
+        int d[4];
+        float v[4];
+        int term;
+    };
+    // Loads the block of (it, istep) for this lane and advances the iterator.  ALWAYS issues its two loads (past the end:
+    // the table's first block, every posting masked), so that the number of loads in flight is a compile-time constant
+    // and the waits before the adds are counted vmcnt waits, not vmcnt(0).
+    auto load = [&](Blk &b) {
+        const bool valid = it < nt;
+        b.term = valid ? it : 0;
+        const int bi = istep * 64 + lane;
+        const bool ok = valid && bi < cnb;
+        int dd[4];
+        float vv[4];
+        load_block(post + (ok ? (cs >> 2) + bi : 0) * BW, VT(), dd, vv);
+        const int head = (int)(cs & 3), span = head + cl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int p = bi * 4 + c;
+            b.d[c] = (ok && p >= head && p < span) ? dd[c] : -1;
+            b.v[c] = vv[c];
+        }
+        if (valid) ++istep;
+    };
+    auto add = [&](const Blk &b) {
+        const float idf = S.m_idf[b.term], qw = S.m_qw[b.term];
+        // branch-free: a masked posting (doc < 0) goes to a private dummy word; one term's docs are distinct
+        float *const dummy = reinterpret_cast<float *>(S.st_off) + lane;
+        float *slot[4];
+        float a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) slot[c] = (b.d[c] >= 0) ? acc + (b.d[c] - (int)tile_base) : dummy;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = *slot[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *slot[c] = a[c] + (b.v[c] * idf) * qw;
+    };
+#ifndef SRX_WDENSE_DEPTH
+#define SRX_WDENSE_DEPTH 8
+#endif
+    constexpr int K = SRX_WDENSE_DEPTH;  // blocks in flight per lane
+    Blk q[K];
+    bool live[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        seek();
+        live[j] = it < nt;
+        load(q[j]);
+    }
+    while (live[0]) {  // set 0 always holds the oldest block at the top of the loop
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            add(q[j]);  // a dead set holds masked postings only: nothing is added
+            seek();
+            live[j] = it < nt;
+            load(q[j]);
+        }
+    }
+}
+
 // Exact k-th largest over n_items keys that STAY IN LDS (keyfn(i) re-reads them in every pass; key 0 = none, keys in
 // [1, 2^31)): MSD radix select with 8-bit digits, one histogram bin per thread (hist = 256 words).  The block-level
 // sibling of wave_radix_kth: no per-thread key arrays, so nothing spills (the register-array form radix_kth<N> cost the
@@ -506,10 +597,10 @@ __device__ unsigned block_radix_kth_lds(KeyFn keyfn, unsigned n_items, unsigned 
 // Fold the positive accumulators of a dense tile into the block's running top-k.  The accumulators stay in LDS: a
 // counting pass, then either an append pass (the common case: the lazy list has room) or an exact selection over
 // (list U tile candidates) whose keys are re-read from LDS.
-__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k) {
+__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
-    const int G = 1 << ix.tile_log2;
+    const int G = span_tiles << ix.tile_log2;  // accumulators in LDS: span_tiles consecutive tiles
     const unsigned tau = S.tk.tau;
     const unsigned n_old = S.tk.count;  // read BEFORE the barriers below
     const int n_valid = (int)min((int64_t)G, ix.n_docs - (int64_t)tile_base);  // docs of this tile that exist
@@ -682,6 +773,39 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             S.m_idf[tid] = ix.idf[term];
             S.m_qw[tid] = q_weight[t0 + tid];
         }
+        // wave-level dense path (tiles of <= 4096 docs, <= 64 terms): lane i of EVERY wave carries term i
+        const bool wave_dense = (4 << ix.tile_log2) <= TBL_WORDS && nt <= 64 && !(dbg & 2048);
+        int64_t wbase = 0;
+        const int32_t *wskip = ix.tile_skip;
+        if (wave_dense && (tid & 63) < nt) {
+            const int term = q_term[t0 + (tid & 63)];
+            wbase = ix.term_ptr[term];
+            wskip = ix.tile_skip + (int64_t)term * row;
+        }
+        auto dense_quads = [&](int ja, int jb) {  // tiles [ja, jb): four at a time, one per wave, no block barriers inside
+            for (int j0 = ja; j0 < jb; j0 += WAVES) {
+                const int j = j0 + (tid >> 6);
+                const bool has_tile = j < jb;
+                int a = 0, b = 0;
+                if (has_tile && (tid & 63) < nt) {
+                    a = wskip[j];
+                    b = wskip[j + 1];
+                }
+                T2(0);
+                wave_dense_accumulate<VT>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a);
+                __syncthreads();
+                T2(3); T2C(11);
+                dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES);
+                T2(4);
+            }
+            for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
+            __syncthreads();
+        };
+        if (all_units && wave_dense) {
+            // tier 2 has the whole query (k or the term count rules tier 1 out): units mean nothing here, the split's tile
+            // range goes through the wave-level dense path in full groups of four tiles
+            dense_quads(su_lo * tps, min(su_hi * tps, ix.n_tiles));
+        } else
         for (int su = su_lo; su < su_hi; ++su) {
             if (!all_units && !((my_ovf[su >> 5] >> (su & 31)) & 1u)) continue;  // uniform
             int lo = 0, hi = 0;
@@ -716,6 +840,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 T2(0);
                 hash_unit<VT>(S, ix, nt, my_len, k, dbg);
                 T2(2); T2C(10);
+            } else if (P > 0 && wave_dense) {
+                dense_quads(su * tps, min(su * tps + tps, ix.n_tiles));
             } else if (P > 0) {
                 // ---- overflow: pack this supertile's tiles greedily into units of <= HASH_CAP postings;
                 //      a single tile above that is accumulated densely ----

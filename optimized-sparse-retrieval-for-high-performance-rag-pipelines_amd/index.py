@@ -460,6 +460,9 @@ class DeviceIndex:
             _capi.check(rc, "srx_search_packed")
         return out
 
+    def validate_queries(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray) -> None:
+        validate_query_batch(q_ptr, q_term, q_weight, self.vocab)
+
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
         """Host arrays in, host arrays out (doc, score, count).  The batch is validated first (``validate_queries``);
         ``search_device`` trusts its device tensors."""
