@@ -83,7 +83,8 @@ WORKLOADS = {
     "c1": dict(n_docs=57_638, vocab=80_000, nnz_per_doc=130, n_queries=100, terms=10, k=10, seed=20251, kind="text"),
     # secondary workloads (BASELINE.json configs[3], configs[4]); single-GPU numbers are reported in DESIGN.md only
     "c4": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20254,
-               kind="splade", tile_log2=12),  # 4096-doc tiles: tier 2's wave-level dense path (four tiles per workgroup)
+               kind="splade", tile_log2=12, unit_tiles=1),  # 4096-doc tiles, runs padded per tile: tier 2's wave-level
+                                                            # dense path in its unmasked form (four tiles per workgroup)
     # dev variant of c4 without hot terms (uniform term ids): every tile holds ~4 k postings of ~50 terms
     "c4u": dict(n_docs=5_000_000, vocab=30_000, nnz_per_doc=150, n_queries=1_000, terms=50, k=1000, seed=20256,
                 kind="splade", zipf_s=0.0),
@@ -153,6 +154,8 @@ def main():
     ap.add_argument("--supertile-log2", type=int, default=0)
     ap.add_argument("--target-blocks", type=int, default=0)
     ap.add_argument("--unit-tiles", type=int, default=0)
+    ap.add_argument("--build-unit-tiles", type=int, default=-1,
+                    help="tiles per padded run of the posting layout (index build); -1 = the workload's, 0 = automatic")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND every oracle check (profiling runs)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation flags (timing experiments only; results are wrong)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
@@ -198,6 +201,8 @@ def main():
     kind = w.get("kind", "uniform")
     if args.tile_log2 == 0:
         args.tile_log2 = w.get("tile_log2", 14)
+    if args.build_unit_tiles < 0:
+        args.build_unit_tiles = w.get("unit_tiles", 0)
     n_docs, V, k, nq = w["n_docs"], w["vocab"], w["k"], w["n_queries"]
     want_check = not args.no_cpu_baseline          # oracle checks (and, at N = 1, the timed CPU baseline)
     want_cpu = want_check and world == 1 and not args.force_dist
@@ -278,7 +283,7 @@ def main():
             del indptr
         ix = sparse_rx.DeviceIndex.from_coo(rows, cols, tf, idf, shard_docs, doc_lengths=dl, k1=1.2, b=0.75, avgdl=avgdl,
                                             device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
-                                            mode="dot" if kind == "splade" else "bm25",
+                                            unit_tiles=args.build_unit_tiles, mode="dot" if kind == "splade" else "bm25",
                                             val_dtype="f16" if kind == "splade" else "f32")
         del rows, cols, tf  # (no empty_cache(): 288 GB of HBM, and freeing would idle the GPU before the timed region)
     ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,

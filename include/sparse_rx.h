@@ -113,7 +113,8 @@ typedef struct {
     int32_t target_blocks;  /* wave-sized work items to aim for (splits of a query / unsplit rounds + split tail); 0 = auto (3072) */
     int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
     int32_t reserved;       /* debug bits.  Exact results: 8 = every query through the tier-2 (block) kernel, 16 = ignore
-                             * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only.  Timing
+                             * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only, 2048 = no wave-level
+                             * dense tiles, 4096 = their masked form even on one-tile units, 8192 = their general selection.  Timing
                              * experiments with WRONG results (bench ablations): 1 = no multi-term doc resolution, 2 = no
                              * candidate screening, 4 = loads only, 32 = no final ranking, 512 = multi-term docs located but
                              * not summed, 1024 = ... summed but not appended. */

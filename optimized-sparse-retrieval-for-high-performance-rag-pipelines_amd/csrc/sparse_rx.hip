@@ -59,6 +59,9 @@ struct ScoreShared {
     int ptile[MAX_TPS + 1];  // overflow packer: postings per tile / group boundaries
     int grp[MAX_TPS + 1];
     int n_grp;
+#ifdef SRX_T2_PAD_WORDS
+    int occupancy_pad[SRX_T2_PAD_WORDS];  // dev experiment: more LDS per workgroup = fewer workgroups per CU
+#endif
 };
 
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
@@ -161,17 +164,16 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
         for (int i = tid; i < G / 4; i += THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    // Batches of 2048 postings (two stripes of whole blocks = 8 postings per thread) are enumerated term-major; the loads
-    // of batch n+1 are issued before batch n is accumulated, across term boundaries too, so 2 x 16 KB per workgroup stay
-    // in flight and a term's load latency hides behind the previous term's work.  A barrier separates consecutive
+    // Batches of 2048 postings (two stripes of whole blocks = 8 postings per thread) are enumerated term-major; a ring
+    // of SRX_DENSE_DEPTH batches is in flight, across term boundaries too, so a term's load latency hides behind the
+    // previous terms' work (one batch ahead left the dense tiles latency-bound).  A barrier separates consecutive
     // batches of different terms (the next term may touch the same doc).  A tile's run [start, start + len) starts at
     // an arbitrary padded position: the batches cover the blocks from start & ~3 on, postings outside the run and
     // sentinels (doc -1) are blanked.
 #ifndef SRX_DENSE_NB
 #define SRX_DENSE_NB 8
 #endif
-    constexpr int NB = SRX_DENSE_NB;      // postings per thread per batch (whole blocks of 4): with one batch ahead, 2 x NB x 8 bytes
-                                          // per thread are in flight (NB = 8 left the dense tiles latency-bound: profiles/r02_c5_*)
+    constexpr int NB = SRX_DENSE_NB;      // postings per thread per batch (whole blocks of 4)
     constexpr int BATCH = THREADS * NB;
     auto next_term = [&](int i) {  // first term index >= i with postings in this tile (uniform), nt if none
         while (i < nt && S.m_len[i] == 0) ++i;
@@ -442,12 +444,17 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
 // Dense accumulation of ONE tile by ONE wavefront (tiles of <= 4096 docs: four waves' accumulators fit the 64 KiB table,
 // so a workgroup takes four consecutive tiles at a time).  No block barrier anywhere: the wave streams the tile's runs
 // term by term in the query's term order and one wave's LDS instructions execute in order, which is all the per-doc
-// summation order needs.  Lane i < nt carries term i's run in this tile (wstart / wlen); the loads of the next blocks
-// (across term boundaries) are in flight while a block is accumulated.  The block kernel's term-by-term form costs a
-// barrier and a memory round trip per term: on 50-term learned-sparse queries (C4) that was 85 % of its time.
-template <typename VT>
+// summation order needs.  Lane i < nt carries term i's run in this tile (wstart / wlen) and its weights (my_idf /
+// my_qw); K blocks per lane are in flight across term boundaries.  The block kernel's term-by-term form costs a barrier
+// and a memory round trip per term: on 50-term learned-sparse queries (C4) that was 85 % of its time.
+// ALIGNED (the index has one-tile units: every run of a tile starts on a block boundary and ends in sentinels): only the
+// sentinel test is left of the masks, idle lanes read their own all-sentinel block.
+// (Measured and dropped: adding with the LDS float atomic ds_add_f32 instead of read / add / write.  It is bit-identical
+// to v_add_f32 and ordered -- tools/lds_fadd_probe.hip -- and needs half the instructions, but the LDS executes it at
+// about one lane every 7 cycles: C4 went from 47 ms to 166 ms per batch.)
+template <typename VT, bool ALIGNED>
 __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int nt, int64_t tile_base, bool has_tile, int64_t wstart,
-                                      int wlen) {
+                                      int wlen, float my_idf, float my_qw) {
     constexpr int BW = BlockWords<VT>::value;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = 1 << ix.tile_log2;
@@ -455,6 +462,7 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
     for (int i = lane; i < G / 4; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!has_tile) return;  // uniform per wave
     const int32_t *post = ix.post;
+    const int64_t idle_blk = ix.zero_block + lane;  // my all-sentinel block
     // iterator over (term, step): 64 blocks per step
     int it = 0, istep = 0;       // next (term, step) to load
     int64_t cs = 0;              // its run start / length (uniform)
@@ -476,40 +484,42 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
     struct Blk {
         int d[4];
         float v[4];
-        int term;
+        float idf, qw;  // uniform
     };
-    // Loads the block of (it, istep) for this lane and advances the iterator.  ALWAYS issues its two loads (past the end:
-    // the table's first block, every posting masked), so that the number of loads in flight is a compile-time constant
-    // and the waits before the adds are counted vmcnt waits, not vmcnt(0).
+    // Loads the block of (it, istep) for this lane and advances the iterator.  ALWAYS issues its loads (past the end: an
+    // all-sentinel block), so that the number of loads in flight is a compile-time constant and the waits before the adds
+    // are counted vmcnt waits, not vmcnt(0).
     auto load = [&](Blk &b) {
         const bool valid = it < nt;
-        b.term = valid ? it : 0;
+        const int t = valid ? it : 0;
+        b.idf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_idf), t));
+        b.qw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_qw), t));
         const int bi = istep * 64 + lane;
         const bool ok = valid && bi < cnb;
         int dd[4];
         float vv[4];
-        load_block(post + (ok ? (cs >> 2) + bi : 0) * BW, VT(), dd, vv);
+        load_block(post + (ok ? (cs >> 2) + bi : idle_blk) * BW, VT(), dd, vv);
         const int head = (int)(cs & 3), span = head + cl;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int p = bi * 4 + c;
-            b.d[c] = (ok && p >= head && p < span) ? dd[c] : -1;
+            b.d[c] = (ALIGNED || (ok && p >= head && p < span)) ? dd[c] : -1;
             b.v[c] = vv[c];
         }
         if (valid) ++istep;
     };
+    // branch-free: a masked posting / sentinel (doc < 0) goes to a private dummy word; one term's docs are distinct
+    float *const dummy = reinterpret_cast<float *>(S.st_off) + lane;
+    float *const acc0 = acc - (int)tile_base;
     auto add = [&](const Blk &b) {
-        const float idf = S.m_idf[b.term], qw = S.m_qw[b.term];
-        // branch-free: a masked posting (doc < 0) goes to a private dummy word; one term's docs are distinct
-        float *const dummy = reinterpret_cast<float *>(S.st_off) + lane;
         float *slot[4];
         float a[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) slot[c] = (b.d[c] >= 0) ? acc + (b.d[c] - (int)tile_base) : dummy;
+        for (int c = 0; c < 4; ++c) slot[c] = (b.d[c] >= 0) ? acc0 + b.d[c] : dummy;
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c] = *slot[c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *slot[c] = a[c] + (b.v[c] * idf) * qw;
+        for (int c = 0; c < 4; ++c) *slot[c] = a[c] + (b.v[c] * b.idf) * b.qw;
     };
 #ifndef SRX_WDENSE_DEPTH
 #define SRX_WDENSE_DEPTH 8
@@ -526,7 +536,7 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
     while (live[0]) {  // set 0 always holds the oldest block at the top of the loop
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            add(q[j]);  // a dead set holds masked postings only: nothing is added
+            add(q[j]);  // a dead set holds sentinels / masked postings only: nothing is added
             seek();
             live[j] = it < nt;
             load(q[j]);
@@ -594,14 +604,127 @@ __device__ unsigned block_radix_kth_lds(KeyFn keyfn, unsigned n_items, unsigned 
     return prefix;
 }
 
+// Running list + overflow area -> the k best, tau = the k-th best.  n_total = entries appended so far: positions
+// [0, KMAX) live in tk.bits / tk.doc, [KMAX, KMAX + OVF_CAP) in ovf_bits / ovf_doc.  Requires KMAX < n_total <=
+// KMAX + OVF_CAP and k <= KMAX.  Every entry is a real candidate (key >= 1).  Same tie rule as everywhere: the smaller
+// doc id wins.  Touches ~1.4 k entries instead of the tile's 16 k accumulators (dense_tile_select's general path).
+constexpr int OVF_CAP = 384;  // (sizeof m_start + sizeof m_len) / 8: those tables are idle on the wave-level dense path
+__device__ void list_compact_select(ScoreShared &S, int k, unsigned n_total, unsigned *ovf_bits, int *ovf_doc) {
+    const int tid = threadIdx.x;
+    unsigned *hist = reinterpret_cast<unsigned *>(S.st_off);
+    auto key1 = [&](unsigned i) -> unsigned { return i < (unsigned)KMAX ? S.tk.bits[i] : ovf_bits[i - KMAX]; };
+    auto doc_of = [&](unsigned i) -> int { return i < (unsigned)KMAX ? S.tk.doc[i] : ovf_doc[i - KMAX]; };
+    constexpr int IPT = (KMAX + OVF_CAP + THREADS - 1) / THREADS;  // entries per thread
+    unsigned ek[IPT];
+    int ed[IPT];
+    unsigned mx = 0, mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const unsigned i = tid + j * THREADS;
+        ek[j] = i < n_total ? key1(i) : 0u;
+        ed[j] = i < n_total ? doc_of(i) : 0;
+        if (ek[j] != 0u) {
+            mx = max(mx, ek[j]);
+            mn = min(mn, ek[j]);
+        }
+    }
+    const SumMaxMin r1 = block_sum_max_min(0u, mx, mn, S.tk.red);
+    unsigned n_gt, n_eq;
+    const unsigned T = block_radix_kth_lds(key1, n_total, (unsigned)k, r1.mx, r1.mn, n_total, hist, S.tk.red, &n_gt, &n_eq);
+    const unsigned need = (unsigned)k - n_gt;  // ties to accept, 1 <= need <= n_eq
+    unsigned T2 = 0;                            // accept ties with 0x7FFFFFFF - doc >= T2 (smaller docs first)
+    if (n_eq > need) {
+        auto key2 = [&](unsigned i) -> unsigned { return key1(i) == T ? 0x7FFFFFFFu - (unsigned)doc_of(i) : 0u; };
+        unsigned mx2 = 0, mn2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+            if (ek[j] == T && ek[j] != 0u) {
+                const unsigned x = 0x7FFFFFFFu - (unsigned)ed[j];
+                mx2 = max(mx2, x);
+                mn2 = min(mn2, x);
+            }
+        const SumMaxMin r2 = block_sum_max_min(0u, mx2, mn2, S.tk.red);
+        unsigned g2, e2;
+        T2 = block_radix_kth_lds(key2, n_total, need, r2.mx, r2.mn, n_eq, hist, S.tk.red, &g2, &e2);
+    }
+    __syncthreads();  // every read of the old entries is done (the registers hold them)
+    if (tid == 0) {
+        S.tk.count = 0;
+        S.tk.tau = T;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+        if (ek[j] != 0u && (ek[j] > T || (ek[j] == T && (0x7FFFFFFFu - (unsigned)ed[j]) >= T2))) {
+            const unsigned p = atomicAdd(&S.tk.count, 1u);
+            S.tk.bits[p] = ek[j];
+            S.tk.doc[p] = ed[j];
+        }
+    __syncthreads();
+}
+
 // Fold the positive accumulators of a dense tile into the block's running top-k.  The accumulators stay in LDS: a
 // counting pass, then either an append pass (the common case: the lazy list has room) or an exact selection over
 // (list U tile candidates) whose keys are re-read from LDS.
-__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1) {
+// n_old_in >= 0 (the wave-level dense path; the caller read tk.count BEFORE its last barrier, and m_start / m_len are idle):
+// one scan appends the candidates to the list and, past its capacity, to an overflow area; a selection then only touches
+// those ~1.4 k entries (list_compact_select).  More candidates than the overflow area holds (a query's first tiles): the
+// appends are rolled back and the general path below runs.
+__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1, int n_old_in = -1) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
     const int G = span_tiles << ix.tile_log2;  // accumulators in LDS: span_tiles consecutive tiles
     const unsigned tau = S.tk.tau;
+    if (n_old_in >= 0) {
+        unsigned *ovf_bits = reinterpret_cast<unsigned *>(S.m_start);
+        int *ovf_doc = reinterpret_cast<int *>(ovf_bits + OVF_CAP);
+        static_assert(sizeof(S.m_start) + sizeof(S.m_len) >= OVF_CAP * 8, "overflow area");
+        // accumulators of docs past n_docs were zeroed and never touched: no bound check
+        const int lane = tid & 63;
+        for (int i = tid; i < G / 4; i += THREADS) {  // G / 4 is a multiple of THREADS: whole waves
+            const float4 a4 = reinterpret_cast<const float4 *>(acc)[i];
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            bool ok[4];
+            unsigned nc = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau;
+                nc += ok[c] ? 1u : 0u;
+            }
+            if (__ballot(nc != 0u) == 0ull) continue;  // the common case once tau has risen
+            unsigned inc = nc;                          // one atomic per wave: inclusive scan of the lanes' counts
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned w = __shfl_up(inc, o);
+                if (lane >= o) inc += w;
+            }
+            unsigned base = 0;
+            if (lane == 63) base = atomicAdd(&S.tk.count, inc);
+            unsigned p = __shfl(base, 63) + inc - nc;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (ok[c]) {
+                    if (p < (unsigned)KMAX) {
+                        S.tk.bits[p] = __float_as_uint(a[c]);
+                        S.tk.doc[p] = tile_base + 4 * i + c;
+                    } else if (p < (unsigned)(KMAX + OVF_CAP)) {
+                        ovf_bits[p - KMAX] = __float_as_uint(a[c]);
+                        ovf_doc[p - KMAX] = tile_base + 4 * i + c;
+                    }
+                    ++p;
+                }
+        }
+        __syncthreads();
+        const unsigned n_total = S.tk.count;
+        if (n_total <= (unsigned)KMAX) return;  // uniform
+        if (n_total <= (unsigned)(KMAX + OVF_CAP)) {
+            list_compact_select(S, k, n_total, ovf_bits, ovf_doc);
+            return;
+        }
+        __syncthreads();
+        if (tid == 0) S.tk.count = (unsigned)n_old_in;  // roll back: entries [n_old, ...) are dropped, the scan below finds them again
+        __syncthreads();
+    }
     const unsigned n_old = S.tk.count;  // read BEFORE the barriers below
     const int n_valid = (int)min((int64_t)G, ix.n_docs - (int64_t)tile_base);  // docs of this tile that exist
     auto cand_key = [&](int o) -> unsigned {  // key of accumulator o: its score bits when it can enter the list, else 0
@@ -736,21 +859,24 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     // initial threshold from the index's per-term score bounds (see srx_wave_kernel): exact lower bound on the
     // k-th best score when every query idf is >= 0
     unsigned tau0 = 0;
+    bool nonfinite = false;
     {
         const int col = bound_column(k);
         unsigned t0b = 0, negf = 0;
         for (int i = tid; i < nt_all; i += THREADS) {
             const int term = q_term[t0 + i];
             const float idf = ix.idf[term], qw = q_weight[t0 + i];
+            if (!(fabsf(idf) <= 3.0e38f) || !(fabsf(qw) <= 3.0e38f)) negf |= 0x10000u;  // inf / nan weight
             if (idf < 0.0f || qw < 0.0f) {
-                negf = 1;
+                negf |= 1u;
             } else if (ix.term_bound != nullptr && col >= 0 && idf > 0.0f && qw > 0.0f) {
                 const float b = 0.0f + (ix.term_bound[(int64_t)term * 4 + col] * idf) * qw;
                 t0b = max(t0b, __float_as_uint(b > 0.0f ? b : 0.0f));
             }
         }
-        const SumMaxMin r = block_sum_max_min(negf, t0b, 0u, S.tk.red);
+        const SumMaxMin r = block_sum_max_min(negf, t0b, 0u, S.tk.red);  // sum: low half = #negative, high half = #non-finite
         tau0 = r.sum ? 0u : r.mx;
+        nonfinite = r.sum >= 0x10000u;
     }
     if (tid == 0) {
         S.tk.count = 0;
@@ -777,11 +903,16 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
         const bool wave_dense = (4 << ix.tile_log2) <= TBL_WORDS && nt <= 64 && !(dbg & 2048);
         int64_t wbase = 0;
         const int32_t *wskip = ix.tile_skip;
+        float w_idf = 0.f, w_qw = 0.f;
         if (wave_dense && (tid & 63) < nt) {
             const int term = q_term[t0 + (tid & 63)];
             wbase = ix.term_ptr[term];
             wskip = ix.tile_skip + (int64_t)term * row;
+            w_idf = ix.idf[term];
+            w_qw = q_weight[t0 + (tid & 63)];
         }
+        // one-tile units + finite weights: the unmasked form (see wave_dense_accumulate)
+        const bool wd_aligned = ix.unit_tiles == 1 && !nonfinite && !(dbg & 4096);
         auto dense_quads = [&](int ja, int jb) {  // tiles [ja, jb): four at a time, one per wave, no block barriers inside
             for (int j0 = ja; j0 < jb; j0 += WAVES) {
                 const int j = j0 + (tid >> 6);
@@ -792,10 +923,14 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     b = wskip[j + 1];
                 }
                 T2(0);
-                wave_dense_accumulate<VT>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a);
+                if (wd_aligned)
+                    wave_dense_accumulate<VT, true>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
+                else
+                    wave_dense_accumulate<VT, false>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
+                const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                 __syncthreads();
                 T2(3); T2C(11);
-                dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES);
+                dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old);
                 T2(4);
             }
             for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode

@@ -173,6 +173,11 @@ def test_zipf_dense_and_overflow_paths(rx):
     ix.set_opts(supertile_log2=16)
     _assert_exact(ix.search(*q, 100), _oracle_batch(c, idf, avgdl, q, 100), "zipf packer")
     ix.close()
+    for ut in (1, 2):  # wave-level dense tiles with negative idf (sentinel contributions are -0), unmasked / masked form
+        ix = _dev_index(rx, c, idf, avgdl, tile_log2=12, unit_tiles=ut)
+        for k in (1000, 300):
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"zipf wave-dense ut={ut} k={k}")
+        ix.close()
 
 
 def test_splade_dot_f16_k1000(rx):
@@ -182,9 +187,14 @@ def test_splade_dot_f16_k1000(rx):
     idf = np.ones(c.vocab, dtype=np.float32)
     q = synth.queries_np(48, c.vocab, 50, seed=9, dist="zipf", s=0.7, weights="learned")
     exp = _oracle_batch(c, idf, 1.0, q, 1000, mode=oracle.MODE_TFIDF_F32)
-    for vd in ("f16", "f32"):
-        ix = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", val_dtype=vd, tile_log2=13)
-        _assert_exact(ix.search(*q, 1000), exp, f"splade {vd}")
+    # tiles of <= 4096 docs: the wave-level dense path (LDS float atomics in term order); one-tile units: its unmasked form
+    for vd, tl, ut in (("f16", 13, 0), ("f32", 13, 0), ("f16", 12, 1), ("f32", 12, 1), ("f16", 12, 4), ("f16", 10, 1), ("f32", 11, 3)):
+        ix = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", val_dtype=vd, tile_log2=tl, unit_tiles=ut)
+        _assert_exact(ix.search(*q, 1000), exp, f"splade {vd} tile={tl} ut={ut}")
+        if tl == 12:
+            for dbg in (2048, 4096, 8192):  # block-level dense tiles / masked form / general selection: same rows
+                ix.set_opts(debug=dbg)
+                _assert_exact(ix.search(*q, 1000), exp, f"splade {vd} tile={tl} ut={ut} debug={dbg}")
         ix.close()
 
 
