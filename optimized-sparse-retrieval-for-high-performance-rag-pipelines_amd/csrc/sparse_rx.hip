@@ -605,7 +605,7 @@ __device__ unsigned block_radix_kth_lds(KeyFn keyfn, unsigned n_items, unsigned 
 }
 
 // Running list + overflow area -> the k best, tau = the k-th best.  n_total = entries appended so far: positions
-// [0, KMAX) live in tk.bits / tk.doc, [KMAX, KMAX + OVF_CAP) in ovf_bits / ovf_doc.  Requires KMAX < n_total <=
+// [0, KMAX) live in tk.bits / tk.doc, [KMAX, KMAX + OVF_CAP) in ovf_bits / ovf_doc.  Requires k <= n_total <=
 // KMAX + OVF_CAP and k <= KMAX.  Every entry is a real candidate (key >= 1).  Same tie rule as everywhere: the smaller
 // doc id wins.  Touches ~1.4 k entries instead of the tile's 16 k accumulators (dense_tile_select's general path).
 constexpr int OVF_CAP = 384;  // (sizeof m_start + sizeof m_len) / 8: those tables are idle on the wave-level dense path
@@ -668,63 +668,70 @@ __device__ void list_compact_select(ScoreShared &S, int k, unsigned n_total, uns
 // (list U tile candidates) whose keys are re-read from LDS.
 // n_old_in >= 0 (the wave-level dense path; the caller read tk.count BEFORE its last barrier, and m_start / m_len are idle):
 // one scan appends the candidates to the list and, past its capacity, to an overflow area; a selection then only touches
-// those ~1.4 k entries (list_compact_select).  More candidates than the overflow area holds (a query's first tiles): the
-// appends are rolled back and the general path below runs.
+// those ~1.4 k entries (list_compact_select), and only when the area is full.  The caller shrinks the list back into
+// tk (dense_list_flush) before anything else reads it.
 __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1, int n_old_in = -1) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
     const int G = span_tiles << ix.tile_log2;  // accumulators in LDS: span_tiles consecutive tiles
-    const unsigned tau = S.tk.tau;
     if (n_old_in >= 0) {
         unsigned *ovf_bits = reinterpret_cast<unsigned *>(S.m_start);
         int *ovf_doc = reinterpret_cast<int *>(ovf_bits + OVF_CAP);
         static_assert(sizeof(S.m_start) + sizeof(S.m_len) >= OVF_CAP * 8, "overflow area");
-        // accumulators of docs past n_docs were zeroed and never touched: no bound check
         const int lane = tid & 63;
-        for (int i = tid; i < G / 4; i += THREADS) {  // G / 4 is a multiple of THREADS: whole waves
-            const float4 a4 = reinterpret_cast<const float4 *>(acc)[i];
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-            bool ok[4];
-            unsigned nc = 0;
+        unsigned n_old = (unsigned)n_old_in;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const unsigned tau_now = S.tk.tau;
+            // accumulators of docs past n_docs were zeroed and never touched: no bound check
+            for (int i = tid; i < G / 4; i += THREADS) {  // G / 4 is a multiple of THREADS: whole waves
+                const float4 a4 = reinterpret_cast<const float4 *>(acc)[i];
+                const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+                bool ok[4];
+                unsigned nc = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau;
-                nc += ok[c] ? 1u : 0u;
-            }
-            if (__ballot(nc != 0u) == 0ull) continue;  // the common case once tau has risen
-            unsigned inc = nc;                          // one atomic per wave: inclusive scan of the lanes' counts
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned w = __shfl_up(inc, o);
-                if (lane >= o) inc += w;
-            }
-            unsigned base = 0;
-            if (lane == 63) base = atomicAdd(&S.tk.count, inc);
-            unsigned p = __shfl(base, 63) + inc - nc;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (ok[c]) {
-                    if (p < (unsigned)KMAX) {
-                        S.tk.bits[p] = __float_as_uint(a[c]);
-                        S.tk.doc[p] = tile_base + 4 * i + c;
-                    } else if (p < (unsigned)(KMAX + OVF_CAP)) {
-                        ovf_bits[p - KMAX] = __float_as_uint(a[c]);
-                        ovf_doc[p - KMAX] = tile_base + 4 * i + c;
-                    }
-                    ++p;
+                for (int c = 0; c < 4; ++c) {
+                    ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now;
+                    nc += ok[c] ? 1u : 0u;
                 }
+                if (__ballot(nc != 0u) == 0ull) continue;  // the common case once tau has risen
+                unsigned inc = nc;                          // one atomic per wave: inclusive scan of the lanes' counts
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned w = __shfl_up(inc, o);
+                    if (lane >= o) inc += w;
+                }
+                unsigned base = 0;
+                if (lane == 63) base = atomicAdd(&S.tk.count, inc);
+                unsigned p = __shfl(base, 63) + inc - nc;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (ok[c]) {
+                        if (p < (unsigned)KMAX) {
+                            S.tk.bits[p] = __float_as_uint(a[c]);
+                            S.tk.doc[p] = tile_base + 4 * i + c;
+                        } else if (p < (unsigned)(KMAX + OVF_CAP)) {
+                            ovf_bits[p - KMAX] = __float_as_uint(a[c]);
+                            ovf_doc[p - KMAX] = tile_base + 4 * i + c;
+                        }
+                        ++p;
+                    }
+            }
+            __syncthreads();
+            const unsigned n_total = S.tk.count;
+            if (n_total <= (unsigned)(KMAX + OVF_CAP)) return;  // uniform.  The list stays lazy: no selection until it is full
+            // The area is full: drop this scan's appends, shrink what was there before to the k best (tau rises) and scan
+            // again.  Still too many (a query's first tiles), or nothing to shrink: the general path below.
+            T2C(14);
+            __syncthreads();
+            if (tid == 0) S.tk.count = n_old;
+            __syncthreads();
+            if (n_old <= (unsigned)k) break;
+            T2C(13);
+            list_compact_select(S, k, n_old, ovf_bits, ovf_doc);
+            n_old = (unsigned)k;
         }
-        __syncthreads();
-        const unsigned n_total = S.tk.count;
-        if (n_total <= (unsigned)KMAX) return;  // uniform
-        if (n_total <= (unsigned)(KMAX + OVF_CAP)) {
-            list_compact_select(S, k, n_total, ovf_bits, ovf_doc);
-            return;
-        }
-        __syncthreads();
-        if (tid == 0) S.tk.count = (unsigned)n_old_in;  // roll back: entries [n_old, ...) are dropped, the scan below finds them again
-        __syncthreads();
     }
+    const unsigned tau = S.tk.tau;
     const unsigned n_old = S.tk.count;  // read BEFORE the barriers below
     const int n_valid = (int)min((int64_t)G, ix.n_docs - (int64_t)tile_base);  // docs of this tile that exist
     auto cand_key = [&](int o) -> unsigned {  // key of accumulator o: its score bits when it can enter the list, else 0
@@ -919,8 +926,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 const bool has_tile = j < jb;
                 int a = 0, b = 0;
                 if (has_tile && (tid & 63) < nt) {
-                    a = wskip[j];
-                    b = wskip[j + 1];
+                    a = gload_i32(wskip + j);
+                    b = gload_i32(wskip + j + 1);
                 }
                 T2(0);
                 if (wd_aligned)
@@ -930,9 +937,11 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                 __syncthreads();
                 T2(3); T2C(11);
-                dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old);
+                if (!(dbg & 16384)) dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old);
                 T2(4);
             }
+            if (S.tk.count > (unsigned)KMAX)  // uniform (stable since the last barrier): the overflow area goes back to its owners
+                list_compact_select(S, k, S.tk.count, reinterpret_cast<unsigned *>(S.m_start), reinterpret_cast<int *>(S.m_start) + OVF_CAP);
             for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
             __syncthreads();
         };
@@ -945,8 +954,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             if (!all_units && !((my_ovf[su >> 5] >> (su & 31)) & 1u)) continue;  // uniform
             int lo = 0, hi = 0;
             if (tid < nt) {
-                lo = skip_row[min(su * tps, ix.n_tiles)];
-                hi = skip_row[min((su + 1) * tps, ix.n_tiles)];
+                lo = gload_i32(skip_row + min(su * tps, ix.n_tiles));
+                hi = gload_i32(skip_row + min((su + 1) * tps, ix.n_tiles));
             }
             const int my_len = hi - lo;
             const unsigned P = block_sum((unsigned)my_len, S.tk.red);

@@ -131,16 +131,28 @@ struct IndexView {
 
 namespace {
 
+// Index arrays are device (global) memory.  Pointers that reach a function through the IndexView reference are generic
+// to the compiler, and a generic load is a FLAT instruction: it counts against lgkmcnt as well as vmcnt, so every LDS wait
+// also drains the posting loads in flight -- which serialised tier 2's prefetch rings behind its LDS round trips.  The
+// round trip through address space 1 makes the loads global_load (vmcnt only).
+#define SRX_GLOBAL __attribute__((address_space(1)))
+typedef int srx_i4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 / 2 words at 4-byte alignment
+typedef int srx_i2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ int gload_i32(const int32_t *p) { return *(const SRX_GLOBAL int32_t *)p; }
+__device__ __forceinline__ srx_i4u gload_i4(const int32_t *p) { return *(const SRX_GLOBAL srx_i4u *)p; }
+__device__ __forceinline__ srx_i2u gload_i2(const int32_t *p) { return *(const SRX_GLOBAL srx_i2u *)p; }
+
 // one posting by padded position (scalar access: tier 2's hash / flat paths)
 template <typename VT>
 __device__ __forceinline__ int post_doc_at(const int32_t *post, int64_t p) {
-    return post[(p >> 2) * BlockWords<VT>::value + (p & 3)];
+    return gload_i32(post + (p >> 2) * BlockWords<VT>::value + (p & 3));
 }
 __device__ __forceinline__ float post_val_at(const int32_t *post, int64_t p, float) {
-    return __int_as_float(post[(p >> 2) * 8 + 4 + (p & 3)]);
+    return __int_as_float(gload_i32(post + (p >> 2) * 8 + 4 + (p & 3)));
 }
 __device__ __forceinline__ float post_val_at(const int32_t *post, int64_t p, __half) {
-    return __half2float(reinterpret_cast<const __half *>(post + (p >> 2) * 6 + 4)[p & 3]);
+    const unsigned w = (unsigned)gload_i32(post + (p >> 2) * 6 + 4 + ((p & 3) >> 1));  // two halves per word
+    return __half2float(__ushort_as_half((unsigned short)((p & 1) ? (w >> 16) : (w & 0xFFFFu))));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,16 +424,16 @@ struct __attribute__((packed, aligned(4))) PackI2 {
 };
 // one block: 4 docs + 4 values (as floats).  `blk` points at the block's first word.
 __device__ __forceinline__ void load_block(const int32_t *blk, float, int (&d)[4], float (&v)[4]) {
-    const PackI4 a = *reinterpret_cast<const PackI4 *>(blk);
-    const PackI4 b = *reinterpret_cast<const PackI4 *>(blk + 4);
+    const srx_i4u a = gload_i4(blk), b = gload_i4(blk + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
     v[0] = __int_as_float(b.x); v[1] = __int_as_float(b.y); v[2] = __int_as_float(b.z); v[3] = __int_as_float(b.w);
 }
 __device__ __forceinline__ void load_block(const int32_t *blk, __half, int (&d)[4], float (&v)[4]) {
-    const PackI4 a = *reinterpret_cast<const PackI4 *>(blk);
-    const PackI2 b = *reinterpret_cast<const PackI2 *>(blk + 4);
+    const srx_i4u a = gload_i4(blk);
+    const srx_i2u b = gload_i2(blk + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-    const __half2 h0 = *reinterpret_cast<const __half2 *>(&b.x), h1 = *reinterpret_cast<const __half2 *>(&b.y);
+    const int bx = b.x, by = b.y;
+    const __half2 h0 = *reinterpret_cast<const __half2 *>(&bx), h1 = *reinterpret_cast<const __half2 *>(&by);
     v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);
 }
 

@@ -16,7 +16,7 @@ L.srx_debug_read_stamps2.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 L.srx_debug_read_stamps2(out)
 names = ["between phases (setup, skip rows, packer)", "flat tiles", "hash units", "dense accumulate", "dense select", "final shrink"]
 tot = sum(out[i] for i in range(6))
-print(f"calls: flat {out[9]}  hash {out[10]}  dense {out[11]}  blocks {out[12]}")
+print(f"calls: flat {out[9]}  hash {out[10]}  dense {out[11]}  blocks {out[12]}  compact selects {out[13]}  general selects after roll-back {out[14]}")
 for i, n in enumerate(names):
     cnt = {1: out[9], 2: out[10], 3: out[11], 4: out[11], 5: out[12]}.get(i, out[12])
     print(f"{n:44s} {100.0 * out[i] / max(tot, 1):6.2f} %   {out[i] / max(cnt, 1):12.0f} ticks/call")
