@@ -522,7 +522,7 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
         for (int c = 0; c < 4; ++c) *slot[c] = a[c] + (b.v[c] * b.idf) * b.qw;
     };
 #ifndef SRX_WDENSE_DEPTH
-#define SRX_WDENSE_DEPTH 8
+#define SRX_WDENSE_DEPTH 4
 #endif
     constexpr int K = SRX_WDENSE_DEPTH;  // blocks in flight per lane
     Blk q[K];
@@ -670,7 +670,8 @@ __device__ void list_compact_select(ScoreShared &S, int k, unsigned n_total, uns
 // one scan appends the candidates to the list and, past its capacity, to an overflow area; a selection then only touches
 // those ~1.4 k entries (list_compact_select), and only when the area is full.  The caller shrinks the list back into
 // tk (dense_list_flush) before anything else reads it.
-__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1, int n_old_in = -1) {
+__device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1, int n_old_in = -1,
+                                  int ovf_cap = 0) {
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
     const int G = span_tiles << ix.tile_log2;  // accumulators in LDS: span_tiles consecutive tiles
@@ -682,9 +683,9 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
         unsigned n_old = (unsigned)n_old_in;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const unsigned tau_now = S.tk.tau;
-            // accumulators of docs past n_docs were zeroed and never touched: no bound check
-            for (int i = tid; i < G / 4; i += THREADS) {  // G / 4 is a multiple of THREADS: whole waves
-                const float4 a4 = reinterpret_cast<const float4 *>(acc)[i];
+            // accumulators of docs past n_docs were zeroed and never touched: no bound check.  G / 4 is a multiple of
+            // THREADS (whole waves run every iteration); four float4 per thread are read before anything is tested
+            auto append4 = [&](int i, const float4 a4) {
                 const float a[4] = {a4.x, a4.y, a4.z, a4.w};
                 bool ok[4];
                 unsigned nc = 0;
@@ -693,8 +694,8 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
                     ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now;
                     nc += ok[c] ? 1u : 0u;
                 }
-                if (__ballot(nc != 0u) == 0ull) continue;  // the common case once tau has risen
-                unsigned inc = nc;                          // one atomic per wave: inclusive scan of the lanes' counts
+                if (__ballot(nc != 0u) == 0ull) return;
+                unsigned inc = nc;  // one atomic per wave: inclusive scan of the lanes' counts
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const unsigned w = __shfl_up(inc, o);
@@ -709,16 +710,36 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
                         if (p < (unsigned)KMAX) {
                             S.tk.bits[p] = __float_as_uint(a[c]);
                             S.tk.doc[p] = tile_base + 4 * i + c;
-                        } else if (p < (unsigned)(KMAX + OVF_CAP)) {
+                        } else if (p < (unsigned)(KMAX + ovf_cap)) {
                             ovf_bits[p - KMAX] = __float_as_uint(a[c]);
                             ovf_doc[p - KMAX] = tile_base + 4 * i + c;
                         }
                         ++p;
                     }
+            };
+            // signed-int order of the bit patterns = float order for x > 0, negatives sort below: a conservative screen
+            const int tau_i = (int)max(tau_now, 1u);
+            const float4 *acc4 = reinterpret_cast<const float4 *>(acc);
+            auto imax4 = [](const float4 r) {
+                return max(max(__float_as_int(r.x), __float_as_int(r.y)), max(__float_as_int(r.z), __float_as_int(r.w)));
+            };
+            const int n4 = G / 4, n4r = (n4 + 63) & ~63;  // whole waves run every iteration (tiny tiles: n4 < 64)
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int i = tid;
+            for (; i + 3 * THREADS < n4; i += 4 * THREADS) {
+                const float4 r0 = acc4[i], r1 = acc4[i + THREADS], r2 = acc4[i + 2 * THREADS], r3 = acc4[i + 3 * THREADS];
+                const int mm = max(max(imax4(r0), imax4(r1)), max(imax4(r2), imax4(r3)));
+                // no accumulator of these 16 x 64 can enter: the common case once tau has risen
+                if (__ballot(mm >= tau_i) == 0ull) continue;
+                append4(i, r0);
+                append4(i + THREADS, r1);
+                append4(i + 2 * THREADS, r2);
+                append4(i + 3 * THREADS, r3);
             }
+            for (; i < n4r; i += THREADS) append4(i, i < n4 ? acc4[i] : zero4);
             __syncthreads();
             const unsigned n_total = S.tk.count;
-            if (n_total <= (unsigned)(KMAX + OVF_CAP)) return;  // uniform.  The list stays lazy: no selection until it is full
+            if (n_total <= (unsigned)(KMAX + ovf_cap)) return;  // uniform.  The list stays lazy: no selection until it is full
             // The area is full: drop this scan's appends, shrink what was there before to the k best (tau rises) and scan
             // again.  Still too many (a query's first tiles), or nothing to shrink: the general path below.
             T2C(14);
@@ -937,7 +958,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                 __syncthreads();
                 T2(3); T2C(11);
-                if (!(dbg & 16384)) dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old);
+                if (!(dbg & 16384)) dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old, OVF_CAP);
                 T2(4);
             }
             if (S.tk.count > (unsigned)KMAX)  // uniform (stable since the last barrier): the overflow area goes back to its owners
@@ -1033,6 +1054,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                         S.m_start[tid] = base + glo;
                         S.m_len[tid] = glen;
                     }
+                    const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                     __syncthreads();
                     if (GP <= (unsigned)DENSE_MIN) {
                         T2(0);
@@ -1043,7 +1065,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                         T2(0);
                         dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
                         T2(3); T2C(11);
-                        dense_tile_select(S, ix, tile_base, k);
+                        dense_tile_select(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);  // m_start / m_len are live: no overflow area
                         T2(4);
                         for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                         __syncthreads();
@@ -1058,6 +1080,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
         const int jb = min(su_hi * tps, ix.n_tiles);
         for (int j = ja; j < jb; ++j) {
             const int tile_base = j << ix.tile_log2;
+            const int n_old = (int)S.tk.count;  // stable: the barrier that opens every pass comes before any append
             for (int pass = 0; pass < n_pass; ++pass) {
                 const int nt = min(MAXT, nt_all - pass * MAXT);
                 __syncthreads();
@@ -1073,7 +1096,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 __syncthreads();
                 dense_tile_accumulate<VT>(S, ix, nt, tile_base, pass == 0);
             }
-            dense_tile_select(S, ix, tile_base, k);
+            dense_tile_select(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);
         }
     }
 
