@@ -37,7 +37,18 @@ __device__ unsigned long long g_stamp2[16];
         }                                                                        \
     } while (0)
 #define T2C(i) do { if (threadIdx.x == 0) atomicAdd(&g_stamp2[i], 1ull); } while (0)
+#define T2L_T0() unsigned long long t2l_prev = __builtin_amdgcn_s_memtime()
+#define T2L(i)                                                                   \
+    do {                                                                         \
+        if (threadIdx.x == 0) {                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();           \
+            atomicAdd(&g_stamp2[i], t_ - t2l_prev);                               \
+            t2l_prev = t_;                                                       \
+        }                                                                        \
+    } while (0)
 #else
+#define T2L_T0() do { } while (0)
+#define T2L(i) do { } while (0)
 #define T2_T0() do { } while (0)
 #define T2(i) do { } while (0)
 #define T2C(i) do { } while (0)
@@ -675,6 +686,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
     const int tid = threadIdx.x;
     const float *acc = reinterpret_cast<const float *>(S.tbl);
     const int G = span_tiles << ix.tile_log2;  // accumulators in LDS: span_tiles consecutive tiles
+    T2L_T0();
     if (n_old_in >= 0) {
         unsigned *ovf_bits = reinterpret_cast<unsigned *>(S.m_start);
         int *ovf_doc = reinterpret_cast<int *>(ovf_bits + OVF_CAP);
@@ -685,28 +697,25 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
             const unsigned tau_now = S.tk.tau;
             // accumulators of docs past n_docs were zeroed and never touched: no bound check.  G / 4 is a multiple of
             // THREADS (whole waves run every iteration); four float4 per thread are read before anything is tested
-            auto append4 = [&](int i, const float4 a4) {
+            auto append4 = [&](int i, const float4 a4) {  // whole waves only
                 const float a[4] = {a4.x, a4.y, a4.z, a4.w};
                 bool ok[4];
-                unsigned nc = 0;
+                unsigned long long m[4];
+                unsigned tot = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now;
-                    nc += ok[c] ? 1u : 0u;
+                    m[c] = __ballot(ok[c]);
+                    tot += (unsigned)__popcll(m[c]);
                 }
-                if (__ballot(nc != 0u) == 0ull) return;
-                unsigned inc = nc;  // one atomic per wave: inclusive scan of the lanes' counts
+                if (tot == 0u) return;  // uniform
+                unsigned base = 0;      // one atomic per wave; a candidate's slot = its rank among the wave's candidates
+                if (lane == 0) base = atomicAdd(&S.tk.count, tot);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned w = __shfl_up(inc, o);
-                    if (lane >= o) inc += w;
-                }
-                unsigned base = 0;
-                if (lane == 63) base = atomicAdd(&S.tk.count, inc);
-                unsigned p = __shfl(base, 63) + inc - nc;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c) {
                     if (ok[c]) {
+                        const unsigned p = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[c], 0u));
                         if (p < (unsigned)KMAX) {
                             S.tk.bits[p] = __float_as_uint(a[c]);
                             S.tk.doc[p] = tile_base + 4 * i + c;
@@ -714,8 +723,9 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
                             ovf_bits[p - KMAX] = __float_as_uint(a[c]);
                             ovf_doc[p - KMAX] = tile_base + 4 * i + c;
                         }
-                        ++p;
                     }
+                    base += (unsigned)__popcll(m[c]);
+                }
             };
             // signed-int order of the bit patterns = float order for x > 0, negatives sort below: a conservative screen
             const int tau_i = (int)max(tau_now, 1u);
@@ -739,6 +749,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
             for (; i < n4r; i += THREADS) append4(i, i < n4 ? acc4[i] : zero4);
             __syncthreads();
             const unsigned n_total = S.tk.count;
+            T2L(6);
             if (n_total <= (unsigned)(KMAX + ovf_cap)) return;  // uniform.  The list stays lazy: no selection until it is full
             // The area is full: drop this scan's appends, shrink what was there before to the k best (tau rises) and scan
             // again.  Still too many (a query's first tiles), or nothing to shrink: the general path below.
@@ -749,6 +760,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
             if (n_old <= (unsigned)k) break;
             T2C(13);
             list_compact_select(S, k, n_old, ovf_bits, ovf_doc);
+            T2L(7);
             n_old = (unsigned)k;
         }
     }

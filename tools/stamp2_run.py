@@ -20,3 +20,4 @@ print(f"calls: flat {out[9]}  hash {out[10]}  dense {out[11]}  blocks {out[12]} 
 for i, n in enumerate(names):
     cnt = {1: out[9], 2: out[10], 3: out[11], 4: out[11], 5: out[12]}.get(i, out[12])
     print(f"{n:44s} {100.0 * out[i] / max(tot, 1):6.2f} %   {out[i] / max(cnt, 1):12.0f} ticks/call")
+print(f"inside dense select: scan+append {out[6] / max(out[11], 1):.0f} ticks/tile-group, compact selects {out[7] / max(out[13], 1):.0f} ticks each ({100.0 * out[7] / max(tot, 1):.2f} % of all)")
