@@ -144,10 +144,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         const int32_t *const zblk = ix.post + (ix.zero_block + lane) * BW;  // my lane's all-sentinel block (doc -1 - 32 lane)
         const int32_t *const tpost = ix.post + (tblk + jl) * BW;       // my lane's first block of the term
 
-        // unit boundary j of my term in BLOCKS from the term's start (#padded postings with doc < j * tpu * G, / 4)
-        auto bound = [&](int j) __attribute__((always_inline)) -> int {
-            return has_term ? (skip_row[min(j * tpu, ix.n_tiles)] >> 2) : 0;
-        };
+        // unit boundary j of my term in padded POSTINGS from the term's start (#padded postings with doc < j * tpu * G; a
+        // multiple of 4).  Loaded by every lane without a branch (lanes without a term read term 0's row: valid memory,
+        // masked where the run length is formed) and consumed SRX_W_DEPTH + 1 fetches later: a load inside a divergent
+        // branch made the compiler finish it on the spot with s_waitcnt vmcnt(0), which also drained the posting loads of
+        // the next unit issued just before it -- the wave then had nothing in flight while it scored.
+        auto bound = [&](int j) __attribute__((always_inline)) -> int { return gload_i32(skip_row + min(j * tpu, ix.n_tiles)); };
 
         // Issue the loads of my term's run [lo, lo + len) (in blocks) of the unit: register r = 4 s + i holds posting i
         // of block s * LPT + jl.  Always exactly 2 * W_R / 4 loads, no branches (idle steps read the sentinel block
@@ -336,15 +338,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             }
         };
         // issue unit su's loads into (d, v); returns its run length (0 past the end; a run that does not fit loads nothing)
-        int bq[SRX_W_DEPTH + 2];  // bq[i] = boundary (next unit to issue) + i, in blocks
+        int bq[SRX_W_DEPTH + 2];  // bq[i] = boundary (next unit to issue) + i, in padded postings
         int su_issue = su_lo;
 #pragma unroll
         for (int i = 0; i < SRX_W_DEPTH + 2; ++i) bq[i] = bound(su_lo + i);
         auto fetch = [&](int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
-            const int len = (su_issue < su_hi) ? bq[1] - bq[0] : 0;
+            const int len = (has_term && su_issue < su_hi) ? (bq[1] - bq[0]) >> 2 : 0;  // blocks
             const bool fit = __ballot(len > (W_R / 4) * LPT) == 0ull;  // uniform: every term's run fits the steps
             STAMP(0);  // loop overhead / previous tail
-            issue(bq[0], fit ? len : 0, d, v);
+            issue(bq[0] >> 2, fit ? len : 0, d, v);
             STAMP(1);  // issue
 #pragma unroll
             for (int i = 0; i < SRX_W_DEPTH + 1; ++i) bq[i] = bq[i + 1];
