@@ -53,7 +53,9 @@ typedef enum {
 /* Limits of this build (srx_limits() returns them at run time). */
 #define SRX_MAX_K 1024         /* largest top-k */
 #define SRX_MAX_TILE_LOG2 14   /* skip-table granularity G = 2^tile_log2 docs, G <= 16384 */
-#define SRX_BLOCK_PAD 64        /* sentinel blocks behind the last run: post must hold n_blocks + SRX_BLOCK_PAD blocks */
+#define SRX_BLOCK_PAD 256       /* sentinel blocks behind the last run: post must hold n_blocks + SRX_BLOCK_PAD blocks; block j of them
+                                 * carries doc -1 - 32 (j mod 64): lane l of a tier-1 wave sends the idle load of step s to block
+                                 * l + s * (lanes per term) <= 63 + 3 * 64, same immediate offset as the real load */
 
 /*
  * Device-resident inverted index of one doc-range shard: term-major postings in BLOCKS + a tile skip table.
@@ -241,6 +243,19 @@ int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k);
 int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
                          int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
                          void *workspace, int64_t workspace_bytes, void *stream, float score_offset);
+
+/* Asymmetric (uint8) scheme of the same retriever: replaces the de-quantize + np.dot loop of
+ * QuantizedEmbeddingRetriever._numpy_quantized_similarity (rag_system/core/retriever_registry.py:550-559) + the top-k
+ * after it (:505-519).  corpus u8[n_docs][dim] (as written by _quantize_embeddings :449-462), corpus_scales f32[2 n_docs] =
+ * the reference's scale table UNCHANGED, read the way its reader reads it: doc d takes scale = corpus_scales[2 d] and
+ * min = corpus_scales[2 d + 1] (:552-553; the writer :459 stores all scales, then all mins -- results follow the
+ * reader, like the reference's).  score[q][d] = sum_i (corpus[d][i] * scale + min) * queries[q][i] in fp32, queries =
+ * the de-quantized fp32 query vectors (u8 * query_scale + query_min, :555), dim a multiple of 64, <= 1024 (pad corpus and
+ * queries with zeros).  Results: the k largest scores > 0, ranked (desc, doc asc).  Workspace:
+ * srx_dense_f32_workspace_bytes.  fp32 summation order differs from the reference's BLAS dot: ~1e-6 relative. */
+int srx_dense_search_u8(int32_t device, const uint8_t *corpus, const float *corpus_scales, int64_t n_docs, int32_t dim,
+                        const float *queries, int32_t nq, int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score,
+                        int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Average over the profiled srx_search calls since the last read (at most the latest 256): h_ms[0] = tier-1
  * wave kernel, h_ms[1] = tier-2 block kernel, h_ms[2] = merge kernel, h_ms[3] = whole call (milliseconds,

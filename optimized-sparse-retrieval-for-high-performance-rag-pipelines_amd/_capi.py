@@ -66,6 +66,7 @@ SYMBOLS = {
     "srx_dense_search_i8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_dense_f32_workspace_bytes": (_I64, [_I32, _I64, _I32]),
     "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP, ctypes.c_float]),
+    "srx_dense_search_u8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_impacts": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I64, _DBL, _DBL, _DBL, _VP, _VP]),
     "srx_build_tile_skip": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "srx_memcpy_async": (ctypes.c_int, [_VP, _VP, _I64, _VP]),

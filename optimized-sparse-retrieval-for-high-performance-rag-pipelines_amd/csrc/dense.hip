@@ -458,6 +458,43 @@ __global__ __launch_bounds__(THREADS) void srx_dense_f32_scores_kernel(const flo
         }
     }
 }
+
+// The asymmetric (uint8) scheme of the same retriever (rag_system/core/retriever_registry.py:449-462, 550-559): the
+// reference de-quantizes both sides in fp32 -- doc_fp32 = u8 * doc_scale + doc_min, the query likewise -- and takes
+// np.dot of the two fp32 vectors.  Same streaming matvec as above with the row de-quantized in registers (one fp32
+// multiply and one add per element, the reference's two operations; the corpus streams as 1 byte per element).
+// scale_min is the reference's corpus_scales table AS ITS READER INDEXES IT: doc d takes [2 d] and [2 d + 1] (:552-553).
+__global__ __launch_bounds__(THREADS) void srx_dense_u8_scores_kernel(const uint8_t *__restrict__ corpus,
+                                                                      const float *__restrict__ scale_min, int64_t n_docs, int dim,
+                                                                      const float *__restrict__ queries, int nqp,
+                                                                      float *__restrict__ scores, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int ns = dim >> 6;
+    float qv[F32_QP][F32_MAXS];
+#pragma unroll
+    for (int q = 0; q < F32_QP; ++q)
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) qv[q][i] = (q < nqp && i < ns) ? queries[(int64_t)q * dim + lane + 64 * i] : 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * WAVES;
+    for (int64_t d = wave; d < n_docs; d += n_waves) {
+        const uint8_t *row = corpus + d * dim;
+        const float sc = scale_min[2 * d], mn = scale_min[2 * d + 1];
+        float r[F32_MAXS];
+#pragma unroll
+        for (int i = 0; i < F32_MAXS; ++i) r[i] = i < ns ? (float)row[lane + 64 * i] * sc + mn : 0.0f;
+#pragma unroll
+        for (int q = 0; q < F32_QP; ++q) {
+            if (q < nqp) {  // uniform
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < F32_MAXS; ++i) a = a + r[i] * qv[q][i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o);
+                if (lane == 0) scores[(int64_t)q * ld + d] = a;
+            }
+        }
+    }
+}
 }  // namespace
 
 SRX_API int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k) {
@@ -467,17 +504,41 @@ SRX_API int64_t srx_dense_f32_workspace_bytes(int32_t nq, int64_t n_docs, int32_
     return (int64_t)F32_QP * ld * 4 + (int64_t)F32_QP * ns * k * 8 + (int64_t)F32_QP * ns * 4 + 1024;
 }
 
+namespace {
+// rows: f32 embeddings (u8_scale_min == nullptr) or uint8 rows de-quantized with u8_scale_min
+int dense_rows_search(const char *who, int32_t device, const void *rows, const float *u8_scale_min, int64_t n_docs, int32_t dim,
+                      const float *queries, int32_t nq, int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score,
+                      int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v, float score_offset);
+}  // namespace
+
 SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_docs, int32_t dim, const float *queries, int32_t nq,
                                  int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score, int32_t *out_count,
                                  void *workspace, int64_t workspace_bytes, void *stream_v, float score_offset) {
-    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: need n_docs > 0, 1 <= k <= 1024%s");
+    return dense_rows_search("srx_dense_search_f32", device, emb, nullptr, n_docs, dim, queries, nq, k, doc_base, out_doc, out_score,
+                             out_count, workspace, workspace_bytes, stream_v, score_offset);
+}
+
+SRX_API int srx_dense_search_u8(int32_t device, const uint8_t *corpus, const float *corpus_scales, int64_t n_docs, int32_t dim,
+                                const float *queries, int32_t nq, int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score,
+                                int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (!corpus_scales) return fail(SRX_ERR_INVALID, "srx_dense_search_u8: null pointer%s");
+    return dense_rows_search("srx_dense_search_u8", device, corpus, corpus_scales, n_docs, dim, queries, nq, k, doc_base, out_doc,
+                             out_score, out_count, workspace, workspace_bytes, stream_v, 0.0f);
+}
+
+namespace {
+int dense_rows_search(const char *who, int32_t device, const void *rows, const float *u8_scale_min, int64_t n_docs, int32_t dim,
+                      const float *queries, int32_t nq, int32_t k, int64_t doc_base, int32_t *out_doc, float *out_score,
+                      int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v, float score_offset) {
+    const float *emb = (const float *)rows;
+    if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "%s: need n_docs > 0, 1 <= k <= 1024", who);
     if (dim <= 0 || dim % 64 != 0 || dim > 64 * F32_MAXS)
-        return fail(SRX_ERR_INVALID, "srx_dense_search_f32: dim must be a multiple of 64, <= 1024 (pad the rows with zeros)%s");
-    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: doc_base + n_docs must fit int32%s");
+        return fail(SRX_ERR_INVALID, "%s: dim must be a multiple of 64, <= 1024 (pad the rows with zeros)", who);
+    if (doc_base < 0 || doc_base + n_docs >= 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "%s: doc_base + n_docs must fit int32", who);
     if (nq == 0) return SRX_OK;
-    if (!emb || !queries || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "srx_dense_search_f32: null pointer%s");
+    if (!emb || !queries || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "%s: null pointer", who);
     const int64_t need = srx_dense_f32_workspace_bytes(nq, n_docs, k);
-    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "srx_dense_search_f32: workspace too small%s");
+    if (!workspace || workspace_bytes < need) return fail(SRX_ERR_NOMEM, "%s: workspace too small", who);
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_v;
     const int64_t ld = (n_docs + 63) / 64 * 64;
@@ -490,8 +551,12 @@ SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_doc
     if (blocks > 256 * 16) blocks = 256 * 16;
     for (int q0 = 0; q0 < nq; q0 += F32_QP) {
         const int qb = nq - q0 < F32_QP ? nq - q0 : F32_QP;
-        hipLaunchKernelGGL(srx_dense_f32_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, emb, n_docs, (int)dim,
-                           queries + (int64_t)q0 * dim, qb, scores, ld, score_offset);
+        if (u8_scale_min == nullptr)
+            hipLaunchKernelGGL(srx_dense_f32_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, emb, n_docs, (int)dim,
+                               queries + (int64_t)q0 * dim, qb, scores, ld, score_offset);
+        else
+            hipLaunchKernelGGL(srx_dense_u8_scores_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, stream, (const uint8_t *)rows,
+                               u8_scale_min, n_docs, (int)dim, queries + (int64_t)q0 * dim, qb, scores, ld);
         hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb, k,
                            ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0,
                            (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr);
@@ -503,3 +568,4 @@ SRX_API int srx_dense_search_f32(int32_t device, const float *emb, int64_t n_doc
     }
     return SRX_OK;
 }
+}  // namespace

@@ -1416,7 +1416,8 @@ __global__ void srx_blocks_sentinel_kernel(int32_t *__restrict__ out_post, int64
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // posting slot
     if (i < 4 * n) {
         int32_t *blk = out_post + (first_block + (i >> 2)) * BW;
-        blk[i & 3] = -1 - 32 * (i >> 2);  // block j: doc -1 - 32 j -> bitmap word 2047 - j: lane j's idle loads hit a word of their own
+        blk[i & 3] = -1 - 32 * ((i >> 2) & 63);  // block j: doc -1 - 32 (j mod 64) -> bitmap word 2047 - j mod 64: the idle loads of one
+                                                // step (blocks lane + const) hit a word of their own per lane
         reinterpret_cast<VT *>(blk + 4)[i & 3] = VT(0.0f);
     }
 }

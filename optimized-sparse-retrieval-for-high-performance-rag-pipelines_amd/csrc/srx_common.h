@@ -462,6 +462,11 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// number of set bits of the wave mask m below this lane (v_mbcnt_lo / v_mbcnt_hi: no 64-bit lane-mask constant to keep in
+// registers -- the compiler hoisted (1 << lane) - 1 out of the unit loop and spilled it to scratch)
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned uniu(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -577,7 +582,7 @@ __device__ __noinline__ unsigned wave_list_select(SH &S, unsigned count, int k) 
         const unsigned long long m = __ballot(take);
         wsync();
         if (take) {
-            const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            const unsigned p = base + lane_rank(m);
             S.lbits[p] = x;
             S.ldoc[p] = dd;
         }
@@ -608,7 +613,7 @@ __device__ __forceinline__ void wave_append(SH &S, WaveTopk &tk, int k, bool can
         const bool c2 = cand && bits >= tk.tau;  // tau may just have risen
         const unsigned long long m2 = __ballot(c2);
         if (c2) {
-            const unsigned p = tk.count + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
+            const unsigned p = tk.count + lane_rank(m2);
             S.lbits[p] = bits;
             S.ldoc[p] = doc;
         }

@@ -44,6 +44,12 @@ namespace {
 #ifndef SRX_W_DEPTH
 #define SRX_W_DEPTH 2  // register sets: units in flight + the one being scored
 #endif
+#ifndef SRX_W_PREFETCH
+#define SRX_W_PREFETCH 0  // 1: touch the lines of the unit after the one being loaded (see fetch).  Measured and left off: with the
+                          // touch's waits counted correctly the C3 batch takes 2.12 ms instead of 1.26 -- every line is requested
+                          // twice (touch, then the real load after the L1 has dropped it) and the L2 / fabric request rate, not
+                          // HBM latency, is what the kernel is up against (loads-only already streams at the HBM ceiling)
+#endif
 struct WaveShared2 {
     static constexpr int LCAP = W1_LCAP;
     static constexpr bool HIST_ALIASES_ZEROED_LDS = true;
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         auto bound = [&](int j) __attribute__((always_inline)) -> int { return gload_i32(skip_row + min(j * tpu, ix.n_tiles)); };
 
         // Issue the loads of my term's run [lo, lo + len) (in blocks) of the unit: register r = 4 s + i holds posting i
-        // of block s * LPT + jl.  Always exactly 2 * W_R / 4 loads, no branches (idle steps read the sentinel block
-        // through a pre-biased pointer, same immediate offset), so that the compiler can wait for THIS unit's data with
+        // of block s * LPT + jl.  Always exactly 2 * W_R / 4 loads, no branches (idle steps read a sentinel block
+        // through the other pointer, same immediate offset), so that the compiler can wait for THIS unit's data with
         // a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
         auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
             const int32_t *p = tpost + (int64_t)lo * BW;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 const bool ok = (s4 << LPT_LOG2) < rem;
                 int dd[4];
                 float vv[4];
-                load_block((ok ? p : zblk - off) + off, VT(), dd, vv);
+                load_block((ok ? p : zblk) + off, VT(), dd, vv);  // idle: sentinel block lane + s4 * LPT (SRX_BLOCK_PAD covers it)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     d[4 * s4 + c] = dd[c];
@@ -338,20 +344,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             }
         };
         // issue unit su's loads into (d, v); returns its run length (0 past the end; a run that does not fit loads nothing)
-        int bq[SRX_W_DEPTH + 2];  // bq[i] = boundary (next unit to issue) + i, in padded postings
+#if SRX_W_PREFETCH
+        int pf_val = 0;
+#endif
+        constexpr int NBQ = SRX_W_DEPTH + 2 + SRX_W_PREFETCH;  // the touch looks one unit further ahead
+        int bq[NBQ];  // bq[i] = boundary (next unit to issue) + i, in padded postings
         int su_issue = su_lo;
 #pragma unroll
-        for (int i = 0; i < SRX_W_DEPTH + 2; ++i) bq[i] = bound(su_lo + i);
+        for (int i = 0; i < NBQ; ++i) bq[i] = bound(su_lo + i);
         auto fetch = [&](int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
             const int len = (has_term && su_issue < su_hi) ? (bq[1] - bq[0]) >> 2 : 0;  // blocks
             const bool fit = __ballot(len > (W_R / 4) * LPT) == 0ull;  // uniform: every term's run fits the steps
             STAMP(0);  // loop overhead / previous tail
+#if SRX_W_PREFETCH
+            {
+                // Touch the 128-byte lines of the unit AFTER the one loaded below (one dword per line, lane jl takes line jl of
+                // my term's run; PF_STRIDE blocks per line): those lines are on their way from HBM to L2 while this unit's
+                // loads are in flight, so the wave keeps two units' worth of requests outstanding with ONE more register --
+                // the kernel is limited by bytes in flight (16 waves per CU x one unit each), and a third register set costs a
+                // wave per SIMD.  The touch is issued BEFORE this unit's loads and its value is consumed at the next fetch:
+                // loads return in order, so a wait for a touch issued AFTER a unit's loads is a wait for that whole unit.
+                sink ^= pf_val;  // the touch issued one fetch ago, older than that fetch's posting loads (a counted wait)
+                constexpr int PF_STRIDE = 128 / (BW * 4);  // whole blocks per line (4 for fp32 values, 5 for fp16)
+                const int nlen = (has_term && su_issue + 1 < su_hi) ? (bq[2] - bq[1]) >> 2 : 0;
+                const int pb = min(PF_STRIDE * jl, nlen - 1);  // the lane after the last whole line takes the run's last block
+                const bool pok = PF_STRIDE * jl < nlen + PF_STRIDE - 1;
+                // lanes with nothing to touch re-read block 0 of their term (valid memory, already cached): no branch, no
+                // second pointer
+                pf_val = gload_i32(tpost + (int64_t)((pok ? (bq[1] >> 2) + pb : jl) - jl) * BW);
+                __builtin_amdgcn_sched_barrier(0);  // the scheduler must not move the touch behind the posting loads
+            }
+#endif
             issue(bq[0] >> 2, fit ? len : 0, d, v);
             STAMP(1);  // issue
 #pragma unroll
-            for (int i = 0; i < SRX_W_DEPTH + 1; ++i) bq[i] = bq[i + 1];
+            for (int i = 0; i < NBQ - 1; ++i) bq[i] = bq[i + 1];
             ++su_issue;
-            bq[SRX_W_DEPTH + 1] = bound(su_issue + SRX_W_DEPTH + 1);  // needed SRX_W_DEPTH units from now (clamped to the row end)
+            bq[NBQ - 1] = bound(su_issue + NBQ - 1);  // needed NBQ - 2 fetches from now (clamped to the row end)
             return len;
         };
 #if SRX_W_DEPTH == 2
@@ -394,6 +423,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         default: run(IntC<6>{}); break;
     }
     if ((a.dbg & (4 | 512)) && sink == 0x7F123457) a.cand_count[list] = sink;  // keeps the loads of the timing experiment alive
+    if (a.nq < 0 && sink == 0x7F123457) a.cand_count[list] = sink;               // never true (nq >= 0): keeps the touch loads alive
     unsigned count = tk.count;
     if (a.dbg & 32) count = 0;  // timing experiment: no final selection / ranking
     if (count > (unsigned)k) {

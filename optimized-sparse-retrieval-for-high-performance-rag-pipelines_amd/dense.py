@@ -1,6 +1,7 @@
 """Dense INT8 side of the same service: the reference's ``QuantizedEmbeddingRetriever`` hot path,
 ``quantized_dot_product_batch`` + top-k (rag_system/core/retriever_registry.py:90-117, 435-463, 465-524), on the HIP
-engine (``srx_dense_search_i8``: one MFMA int8 GEMM, fp64 scaling like the reference's NumPy scalars, exact top-k).
+engine (``srx_dense_search_i8``: one MFMA int8 GEMM, fp64 scaling like the reference's NumPy scalars, exact top-k), and
+its asymmetric uint8 scheme (:449-462, 550-559; ``srx_dense_search_u8``).
 
 Embedding *generation* stays outside (the reference simulates it from ``hash(text)``); this module starts from the
 embeddings, like the kernel-level functions of the reference do."""
@@ -27,6 +28,31 @@ def quantize_query_symmetric(query_embedding: np.ndarray) -> Tuple[np.ndarray, n
     x = np.asarray(query_embedding)
     s = np.max(np.abs(x))
     return np.round(x / s * 127.0).astype(np.int8), np.array([s / 127.0], dtype=np.float32)[0]
+
+
+def quantize_asymmetric(embeddings: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """retriever_registry.py:449-462: per-row min / max, scale = (max - min) / 255 (>= 1e-8), u8 = round((x - min) / scale);
+    the table is all scales followed by all mins (f32[2 n]), exactly as the reference stores it."""
+    e = np.asarray(embeddings)
+    min_vals = np.min(e, axis=1, keepdims=True)
+    max_vals = np.max(e, axis=1, keepdims=True)
+    scales = np.maximum((max_vals - min_vals) / 255.0, 1e-8)
+    q = np.round((e - min_vals) / scales).astype(np.uint8)
+    return q, np.concatenate([scales.flatten(), min_vals.flatten()]).astype(np.float32)
+
+
+def quantize_query_asymmetric(query_embedding: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """retriever_registry.py:486-491: u8 = round((x - min) / ((max - min) / 255)), query_scales = f32[scale, min]."""
+    x = np.asarray(query_embedding)
+    qmin, qmax = np.min(x), np.max(x)
+    scale = (qmax - qmin) / 255.0
+    return np.round((x - qmin) / scale).astype(np.uint8), np.array([scale, qmin], dtype=np.float32)
+
+
+def dequantize_query_asymmetric(query_uint8: np.ndarray, query_scales: np.ndarray) -> np.ndarray:
+    """retriever_registry.py:555: query_fp32 = u8.astype(f32) * query_scale + query_min (f32 scalars)."""
+    query_scale, query_min = query_scales
+    return query_uint8.astype(np.float32) * query_scale + query_min
 
 
 def _pad_dim(dim: int) -> int:
@@ -89,6 +115,65 @@ class DenseInt8Index:
         torch = _torch()
         d, s, n = self.search_device(torch.as_tensor(np.ascontiguousarray(queries_int8, dtype=np.int8), device=self.device),
                                      torch.as_tensor(np.ascontiguousarray(query_scales, dtype=np.float32), device=self.device), k)
+        torch.cuda.synchronize(self.device)
+        return d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()
+
+
+class DenseUint8Index:
+    """Asymmetric-scheme corpus resident in HBM: ``corpus_uint8`` u8[n_docs, dim] and the reference's ``corpus_scales``
+    table f32[2 n_docs] unchanged (retriever_registry.py:449-462); ``search`` replaces the de-quantize + ``np.dot`` loop of
+    ``_numpy_quantized_similarity`` (:550-559) + the top-k for a batch of de-quantized query vectors
+    (``srx_dense_search_u8``, which indexes the table the way the reference's reader does)."""
+
+    def __init__(self, corpus_uint8, corpus_scales, device="cuda:0", doc_base: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.SparseRxUnavailable("no HIP device visible: DenseUint8Index needs a GPU (there is no CPU fallback)")
+        _capi.lib()
+        self.device = torch.device(device)
+        c = torch.as_tensor(np.ascontiguousarray(corpus_uint8, dtype=np.uint8))
+        assert c.dim() == 2
+        self.n_docs, self.dim = int(c.shape[0]), int(c.shape[1])
+        self.dim_pad = (self.dim + 63) // 64 * 64
+        if self.dim_pad > 1024:
+            raise ValueError(f"embedding dim {self.dim} > 1024 is not supported by the uint8 engine")
+        s = np.ascontiguousarray(corpus_scales, dtype=np.float32).reshape(-1)
+        if s.size != 2 * self.n_docs:
+            raise ValueError("corpus_scales must hold 2 * n_docs floats (retriever_registry.py:459)")
+        with torch.cuda.device(self.device):
+            self.corpus = torch.zeros((self.n_docs, self.dim_pad), dtype=torch.uint8, device=self.device)
+            self.corpus[:, : self.dim] = c.to(self.device)
+            self.scales = torch.as_tensor(s).to(self.device)
+        self.doc_base = int(doc_base)
+        self._ws = None
+
+    def search_device(self, queries_f32, k: int):
+        torch = _torch()
+        if not (1 <= k <= _capi.limits()["max_k"]):
+            raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
+        nq = int(queries_f32.shape[0])
+        L = _capi.lib()
+        with torch.cuda.device(self.device):
+            q = torch.zeros((nq, self.dim_pad), dtype=torch.float32, device=self.device)
+            q[:, : self.dim] = queries_f32
+            out = (torch.empty((nq, k), dtype=torch.int32, device=self.device), torch.empty((nq, k), dtype=torch.float32, device=self.device),
+                   torch.empty((nq,), dtype=torch.int32, device=self.device))
+            if nq == 0:
+                return out
+            need = _capi.check(L.srx_dense_f32_workspace_bytes(nq, self.n_docs, k), "srx_dense_f32_workspace_bytes")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            rc = L.srx_dense_search_u8(self.device.index or 0, _ptr(self.corpus), _ptr(self.scales), self.n_docs, self.dim_pad, _ptr(q),
+                                       nq, k, self.doc_base, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(self._ws),
+                                       self._ws.numel(), _stream_ptr(torch, self.device))
+            _capi.check(rc, "srx_dense_search_u8")
+        return out
+
+    def search(self, queries_uint8: np.ndarray, query_scales: np.ndarray, k: int):
+        """queries u8[nq, dim] + f32[nq, 2] (scale, min) as the reference's search builds them (:486-491); host arrays out."""
+        torch = _torch()
+        qf = np.stack([dequantize_query_asymmetric(q, s) for q, s in zip(np.asarray(queries_uint8), np.asarray(query_scales))])
+        d, s, n = self.search_device(torch.as_tensor(np.ascontiguousarray(qf, dtype=np.float32), device=self.device), k)
         torch.cuda.synchronize(self.device)
         return d.cpu().numpy(), s.cpu().numpy(), n.cpu().numpy()
 

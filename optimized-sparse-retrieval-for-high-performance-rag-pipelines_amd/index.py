@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-BLOCK_PAD = 64  # SRX_BLOCK_PAD in include/sparse_rx.h: all-sentinel blocks behind the last run
+BLOCK_PAD = 256  # SRX_BLOCK_PAD in include/sparse_rx.h: all-sentinel blocks behind the last run
 _TOKEN_RE = re.compile(r"\b\w+\b")
 
 

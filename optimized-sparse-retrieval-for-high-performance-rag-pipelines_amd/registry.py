@@ -199,8 +199,9 @@ def load_index_npz(path) -> HostIndex:
 class QuantizedEmbeddingRetriever:
     """Mirror of the reference's dense retriever (retriever_registry.py:358-559) on the HIP engine: the same simulated
     embeddings (clustered corpus vectors from ``np.random.seed(42)``, query vectors seeded by ``hash(query_text)``), the
-    symmetric INT8 quantization and result dicts, with ``quantized_dot_product_batch`` + top-k replaced by
-    ``srx_dense_search_i8`` (``use_quantization=False``: ``np.dot`` + top-k replaced by ``srx_dense_search_f32``).  All
+    symmetric INT8 / asymmetric uint8 quantization and result dicts, with ``quantized_dot_product_batch`` + top-k replaced by
+    ``srx_dense_search_i8`` (asymmetric: ``srx_dense_search_u8``; ``use_quantization=False``: ``np.dot`` + top-k replaced by
+    ``srx_dense_search_f32``).  All
     queries of a ``search`` call go to the GPU as one batch."""
 
     def __init__(self, method: str, model: str, embedding_dim: int = 768, device: str = "cuda:0", **kwargs):
@@ -209,8 +210,6 @@ class QuantizedEmbeddingRetriever:
         self.embedding_dim = embedding_dim
         self.use_quantization = kwargs.get("use_quantization", True)
         self.quantization_method = kwargs.get("quantization_method", "symmetric")
-        if self.use_quantization and self.quantization_method != "symmetric":
-            raise NotImplementedError("only the reference's default symmetric INT8 scheme is built (retriever_registry.py:437-447)")
         self.device = device
         self.corpus_embeddings_int8: Optional[np.ndarray] = None
         self.corpus_scales: Optional[np.ndarray] = None
@@ -240,18 +239,21 @@ class QuantizedEmbeddingRetriever:
         return self.query_embedding_from_seed(hash(query_text) % (2 ** 31))  # process-dependent, like the reference's
 
     def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
-        from .dense import DenseF32Index, DenseInt8Index, quantize_symmetric
+        from .dense import DenseF32Index, DenseInt8Index, DenseUint8Index, quantize_asymmetric, quantize_symmetric
         self.doc_ids = list(corpus.keys())
         emb = self.synthetic_embeddings(len(corpus))
-        if self.use_quantization:
+        if self.use_quantization and self.quantization_method == "symmetric":
             self.corpus_embeddings_int8, self.corpus_scales = quantize_symmetric(emb)
             self._index = DenseInt8Index(self.corpus_embeddings_int8, self.corpus_scales, device=self.device)
+        elif self.use_quantization:  # any other value is the asymmetric scheme, like the reference's else branch (:449)
+            self.corpus_embeddings_int8, self.corpus_scales = quantize_asymmetric(emb)
+            self._index = DenseUint8Index(self.corpus_embeddings_int8, self.corpus_scales, device=self.device)
         else:
             self.corpus_embeddings_fp32 = emb
             self._index = DenseF32Index(emb, device=self.device)
 
     def search(self, queries: Dict[str, str], top_k: int = 10) -> Dict[str, Dict[str, float]]:
-        from .dense import quantize_query_symmetric
+        from .dense import quantize_query_asymmetric, quantize_query_symmetric
         if self._index is None:
             raise ValueError("Index not built. Call build_index_from_corpus() first.")
         results: Dict[str, Dict[str, float]] = {qid: {} for qid in queries}
@@ -260,9 +262,12 @@ class QuantizedEmbeddingRetriever:
             return results
         embs = [self._generate_query_embedding(text) for _, text in live]
         k = max(1, min(int(top_k), len(self.doc_ids)))
-        if self.use_quantization:
+        if self.use_quantization and self.quantization_method == "symmetric":
             qq = [quantize_query_symmetric(e) for e in embs]
             d, s, n = self._index.search(np.stack([a for a, _ in qq]), np.array([b for _, b in qq], dtype=np.float32), k)
+        elif self.use_quantization:
+            qq = [quantize_query_asymmetric(e) for e in embs]
+            d, s, n = self._index.search(np.stack([a for a, _ in qq]), np.stack([b for _, b in qq]), k)
         else:
             d, s, n = self._index.search(np.stack(embs), k)
         for i, (qid, _) in enumerate(live):

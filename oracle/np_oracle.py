@@ -106,3 +106,19 @@ def f32_similarities(embeddings, queries):
     e = np.asarray(embeddings, dtype=np.float32).astype(np.float64)
     q = np.asarray(queries, dtype=np.float32).astype(np.float64)
     return (q @ e.T).astype(np.float32)
+
+
+def uint8_asymmetric_similarities(queries_uint8, query_scales, corpus_uint8, corpus_scales):
+    """retriever_registry.py:550-559 (asymmetric scheme of _numpy_quantized_similarity): for doc i the reader takes
+    doc_scale = corpus_scales[2 i], doc_min = corpus_scales[2 i + 1] from the table the writer stored as all scales then
+    all mins (:459) -- restated as the reader does it; query_fp32 = u8 * query_scale + query_min and
+    doc_fp32 = u8 * doc_scale + doc_min in fp32, similarities[i] = np.dot(query_fp32, doc_fp32).  The dot is evaluated in
+    float64 and rounded: the reference's fp32 BLAS dot differs by its (unspecified) summation order only."""
+    cs = np.asarray(corpus_scales, dtype=np.float32).reshape(-1)
+    c = np.asarray(corpus_uint8)
+    n = c.shape[0]
+    doc_scale, doc_min = cs[0:2 * n:2], cs[1:2 * n:2]
+    doc = c.astype(np.float32) * doc_scale[:, None] + doc_min[:, None]
+    qs = np.asarray(query_scales, dtype=np.float32).reshape(-1, 2)
+    q = np.asarray(queries_uint8).astype(np.float32) * qs[:, 0:1] + qs[:, 1:2]
+    return (q.astype(np.float64) @ doc.astype(np.float64).T).astype(np.float32)

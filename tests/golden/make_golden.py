@@ -24,6 +24,7 @@ reference produced for them:
   ref_cache/*.npz      the ``.rag_cache/{method}_index_{hash}.npz`` files the reference itself wrote
                        (``_save_cached_index``, :280-296) for the bm25 and splade types -- data files, read with
                        ``allow_pickle=False``
+  dense_uint8_asym.npz/.json  the same retriever with quantization_method="asymmetric" (uint8 + scale / min table)
   dense_int8.npz/.json ``QuantizedEmbeddingRetriever`` (symmetric INT8): quantized corpus, per-query similarity rows
                        and ``search`` results for recorded embeddings (run with the argument ``dense`` to refresh
                        only these)
@@ -349,6 +350,26 @@ def make_dense_fixture():
         qtext = "what is sparse retrieval"
         qseed = hash(qtext) % (2 ** 31)
         qsyn = r2._generate_query_embedding(qtext)
+        # the asymmetric (uint8) scheme: same embeddings through the reference's other branch (:449-462, 486-491, 550-559)
+        ra = ref_reg.QuantizedEmbeddingRetriever("dpr", "fixture", embedding_dim=dim, quantization_method="asymmetric")
+        ra.doc_ids = list(r.doc_ids)
+        ra.corpus_embeddings_int8, ra.corpus_scales = ra._quantize_embeddings(emb)
+        ra._generate_query_embedding = lambda text: lookup[text]
+        asims, aq8, aqs = [], [], []
+        for i in range(nq):
+            qmin, qmax = np.min(qemb[i]), np.max(qemb[i])
+            qscale = (qmax - qmin) / 255.0
+            q8 = np.round((qemb[i] - qmin) / qscale).astype(np.uint8)
+            qsc2 = np.array([qscale, qmin], dtype=np.float32)
+            asims.append(ra._numpy_quantized_similarity(q8, qsc2).copy())
+            aq8.append(q8)
+            aqs.append(qsc2)
+        aresults = {str(k): ra.search(qtexts, top_k=k) for k in (5, 20)}
+    np.savez_compressed(os.path.join(OUT, "dense_uint8_asym.npz"), corpus_uint8=ra.corpus_embeddings_int8,
+                        corpus_scales=ra.corpus_scales, query_uint8=np.stack(aq8), query_scales=np.stack(aqs),
+                        similarities=np.stack(asims))
+    with open(os.path.join(OUT, "dense_uint8_asym.json"), "w", encoding="utf-8") as f:
+        json.dump({"doc_ids": ra.doc_ids, "qids": list(qtexts), "results": aresults}, f, indent=0)
     np.savez_compressed(os.path.join(OUT, "dense_synth.npz"), synthetic_137x24=syn, query_seed=np.int64(qseed), query_24=qsyn)
     np.savez_compressed(os.path.join(OUT, "dense_int8.npz"), emb=emb, qemb=qemb, corpus_int8=r.corpus_embeddings_int8,
                         corpus_scales=r.corpus_scales, query_int8=np.stack(qi8), query_scales=np.array(qsc, dtype=np.float32),

@@ -50,7 +50,7 @@ def assert_canonical_order(docs, scores, label=""):
         assert s[i - 1] > s[i] or (s[i - 1] == s[i] and d[i - 1] < d[i]), f"{label}: order violated at {i}"
 
 
-def np_build_blocks(indptr, indices, data, n_docs, vocab, tile_log2, unit_tiles, val_dtype=np.float32, block_pad=64):
+def np_build_blocks(indptr, indices, data, n_docs, vocab, tile_log2, unit_tiles, val_dtype=np.float32, block_pad=256):
     """NumPy restatement of the blocked posting layout (include/sparse_rx.h, srx_index_desc) from a doc-major CSR whose
     `data` are already the values to store.  Returns (term_ptr i64[V+1], post i32[(n_blocks+pad)*words],
     tile_skip i32[V*(n_tiles+1)], n_blocks).  Slow, small cases only: the checker of srx_build_blocks."""
@@ -89,7 +89,7 @@ def np_build_blocks(indptr, indices, data, n_docs, vocab, tile_log2, unit_tiles,
                 skip[t, j] = unit_start[u] + int(((docs >= u * U) & (docs < j * G)).sum())
     term_ptr[vocab] = pos
     n_blocks = pos // 4
-    dd = np.concatenate(docs_out + [np.repeat(-1 - 32 * np.arange(block_pad, dtype=np.int64), 4)]).astype(np.int32).reshape(-1, 4)
+    dd = np.concatenate(docs_out + [np.repeat(-1 - 32 * (np.arange(block_pad, dtype=np.int64) % 64), 4)]).astype(np.int32).reshape(-1, 4)
     vv = np.concatenate(vals_out + [np.zeros(4 * block_pad, np.float32)]).astype(val_dtype).reshape(-1, 4)
     post = np.zeros((n_blocks + block_pad, words), np.int32)
     post[:, :4] = dd

@@ -132,7 +132,7 @@ def _consistent_shard(rng, V=37, n_docs=5000, tile_log2=11, unit_tiles=2, val_dt
     arrays = {"term_ptr": term_ptr, "post": post, "tile_skip": skip, "idf": rng.random(V).astype(np.float32),
               "term_bound": rng.random(V * 4).astype(np.float32)}
     meta = {"n_docs": n_docs, "vocab": V, "nnz": len(cols), "n_blocks": n_blocks, "doc_base": 123456789012, "tile_log2": tile_log2,
-            "unit_tiles": unit_tiles, "val_type": 1 if val_dtype == np.float16 else 0, "block_pad": 64}
+            "unit_tiles": unit_tiles, "val_type": 1 if val_dtype == np.float16 else 0, "block_pad": 256}
     return arrays, meta
 
 

@@ -208,8 +208,7 @@ def test_simulated_embedding_generators_match_reference(golden_dir):
     assert syn.dtype == np.float32 and np.array_equal(syn.view(np.uint32), z["synthetic_137x24"].view(np.uint32))
     qe = r.query_embedding_from_seed(int(z["query_seed"]))
     assert qe.dtype == np.float32 and np.array_equal(qe.view(np.uint32), z["query_24"].view(np.uint32))
-    with pytest.raises(NotImplementedError):
-        sparse_rx.QuantizedEmbeddingRetriever("dpr", "x", quantization_method="asymmetric")
+    assert sparse_rx.QuantizedEmbeddingRetriever("dpr", "x", quantization_method="asymmetric").quantization_method == "asymmetric"
     assert isinstance(sparse_rx.RetrieverRegistry.create({"type": "dpr", "params": {"embedding_dim": 64}}), sparse_rx.QuantizedEmbeddingRetriever)
 
 
@@ -235,3 +234,91 @@ def test_quantized_embedding_retriever_end_to_end():
     exp = np.dot(f.corpus_embeddings_fp32, f._generate_query_embedding("alpha beta"))
     order = [i for i in np.argsort(-exp) if exp[i] > 0][:5]
     assert list(gf) == [f.doc_ids[i] for i in order] and np.allclose(list(gf.values()), exp[order], rtol=1e-5, atol=1e-6)
+
+
+# ---- asymmetric (uint8) scheme: retriever_registry.py:449-462 (writer), 486-491 (query), 550-559 (similarity) ----
+@pytest.fixture(scope="module")
+def asym_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "dense_uint8_asym.npz"))
+    j = json.load(open(os.path.join(golden_dir, "dense_uint8_asym.json")))
+    e = np.load(os.path.join(golden_dir, "dense_int8.npz"))  # the same embeddings went through both schemes
+    return z, j, e
+
+
+def _same_ranking_within(got_ids, got_scores, exp: dict, rtol=1e-5):
+    """Scores agree rank by rank within the fp32 dot's summation-order tolerance; ids agree wherever the expected
+    neighbours are further apart than that tolerance (the reference's BLAS order is unspecified).  The de-quantized
+    vectors are not normalised (the reader's scale / min indexing makes some rows large), and the error of an fp32 dot
+    scales with sum |q_i d_i|, not with the result: the absolute tolerance follows the largest score of the row."""
+    ev = np.array(list(exp.values()), dtype=np.float64)
+    atol = 1e-6 * max(1.0, float(np.max(np.abs(ev))) if len(ev) else 1.0)
+    assert len(got_ids) == len(exp)
+    assert np.allclose(np.array(got_scores, dtype=np.float64), ev, rtol=rtol, atol=atol)
+    ids = list(exp)
+    for r, did in enumerate(ids):
+        lo = abs(ev[r] - ev[r - 1]) if r > 0 else np.inf
+        hi = abs(ev[r] - ev[r + 1]) if r + 1 < len(ev) else np.inf
+        if min(lo, hi) > 4 * (atol + rtol * abs(ev[r])):
+            assert got_ids[r] == did
+
+
+def test_asymmetric_quantizers_match_reference(asym_golden):
+    z, _, e = asym_golden
+    q, s = sparse_rx.quantize_asymmetric(e["emb"])
+    assert q.dtype == np.uint8 and np.array_equal(q, z["corpus_uint8"])
+    assert s.dtype == np.float32 and s.shape == (2 * len(q),) and np.array_equal(s.view(np.uint32), z["corpus_scales"].view(np.uint32))
+    for i in range(len(e["qemb"])):
+        q8, qs = sparse_rx.quantize_query_asymmetric(e["qemb"][i])
+        assert q8.dtype == np.uint8 and np.array_equal(q8, z["query_uint8"][i])
+        assert np.array_equal(qs.view(np.uint32), z["query_scales"][i].view(np.uint32))
+
+
+def test_asymmetric_oracle_matches_reference(asym_golden):
+    """The restated similarity (the reader's [2 i], [2 i + 1] indexing of the concatenated table included) against the
+    rows the reference computed: fp32 BLAS dot vs float64 dot, so a tolerance; and the recorded search results."""
+    z, j, _ = asym_golden
+    sims = np_oracle.uint8_asymmetric_similarities(z["query_uint8"], z["query_scales"], z["corpus_uint8"], z["corpus_scales"])
+    assert np.allclose(sims, z["similarities"], rtol=1e-5, atol=1e-6 * float(np.max(np.abs(z["similarities"]))))
+    for k_s, res in j["results"].items():
+        d, s, n = np_oracle.dense_topk(sims, int(k_s))
+        for i, qid in enumerate(j["qids"]):
+            _same_ranking_within([j["doc_ids"][x] for x in d[i, : n[i]]], list(s[i, : n[i]]), res[qid])
+
+
+@pytest.mark.gpu
+def test_dense_uint8_asymmetric_reference_fixture(asym_golden):
+    """srx_dense_search_u8 on the reference's own quantized arrays against the results its search recorded."""
+    z, j, _ = asym_golden
+    ix = sparse_rx.DenseUint8Index(z["corpus_uint8"], z["corpus_scales"])
+    for k_s, res in j["results"].items():
+        d, s, n = ix.search(z["query_uint8"], z["query_scales"], int(k_s))
+        for i, qid in enumerate(j["qids"]):
+            _same_ranking_within([j["doc_ids"][x] for x in d[i, : n[i]]], list(s[i, : n[i]]), res[qid])
+
+
+@pytest.mark.gpu
+def test_dense_uint8_asymmetric_vs_oracle_and_registry():
+    rng = np.random.default_rng(77)
+    n_docs, dim, nq, k = 5000, 200, 9, 64   # dim not a multiple of 64: rows are zero-padded on both sides
+    emb = rng.standard_normal((n_docs, dim)).astype(np.float32)
+    qe = rng.standard_normal((nq, dim)).astype(np.float32)
+    c8, cs = sparse_rx.quantize_asymmetric(emb)
+    qq = [sparse_rx.quantize_query_asymmetric(x) for x in qe]
+    q8, qs = np.stack([a for a, _ in qq]), np.stack([b for _, b in qq])
+    ix = sparse_rx.DenseUint8Index(c8, cs)
+    d, s, n = ix.search(q8, qs, k)
+    sims = np_oracle.uint8_asymmetric_similarities(q8, qs, c8, cs)
+    ed, es, en = np_oracle.dense_topk(sims, k)
+    assert np.array_equal(n, en)
+    for i in range(nq):
+        _same_ranking_within(list(d[i, : n[i]]), list(s[i, : n[i]]), {int(a): float(b) for a, b in zip(ed[i, : en[i]], es[i, : en[i]])})
+    # registry-created retriever with the asymmetric scheme
+    corpus = {f"doc{i}": {"text": f"t{i}"} for i in range(300)}
+    r = sparse_rx.RetrieverRegistry.create({"type": "dpr", "params": {"embedding_dim": 96, "quantization_method": "asymmetric"}})
+    r.build_index_from_corpus(corpus)
+    got = r.search({"a": "alpha beta", "b": ""}, top_k=6)
+    assert got["b"] == {}
+    a8, asc = sparse_rx.quantize_query_asymmetric(r._generate_query_embedding("alpha beta"))
+    sims = np_oracle.uint8_asymmetric_similarities(a8[None, :], asc[None, :], r.corpus_embeddings_int8, r.corpus_scales)
+    ed, es, en = np_oracle.dense_topk(sims, 6)
+    _same_ranking_within(list(got["a"]), list(got["a"].values()), {r.doc_ids[int(a)]: float(b) for a, b in zip(ed[0, : en[0]], es[0, : en[0]])})

@@ -409,8 +409,7 @@ def test_registry_twin_golden(rx, golden_dir, tmp_path):
                                     np.array(list(e.values()), np.float32), k=int(k), label=f"{name} k={k} {qid}")
         r.close()
     assert isinstance(rx.RetrieverRegistry.create({"type": "dpr"}), rx.QuantizedEmbeddingRetriever)  # retriever_registry.py:588-592
-    with pytest.raises(NotImplementedError):
-        rx.RetrieverRegistry.create({"type": "dpr", "params": {"quantization_method": "asymmetric"}})
+    assert rx.RetrieverRegistry.create({"type": "dpr", "params": {"quantization_method": "asymmetric"}}).quantization_method == "asymmetric"
     with pytest.raises(ValueError):
         rx.RetrieverRegistry.create({"type": "nope"})
 
