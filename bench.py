@@ -19,7 +19,10 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Fields beyond the
                                D2H of the nq x k result rows on copy streams, overlapped with the search of the next
                                batch) -- SURVEY.md 8(d)'s "batch wall time incl. H2D and D2H"
   roofline.achieved / frac     algorithmic bytes of one step / the scoring kernels' time per step (hipEvents recorded on
-                               the search stream around the kernels inside the timed region)  -- the kernel's roofline
+                               the search stream around the kernels inside the timed region)  -- the kernel's roofline.
+                               Bytes per posting = what the dominant kernel streams (roofline.bytes_per_posting: 6 for the
+                               tier-1 kernel on fp32 values = 16-bit local doc id + value; SURVEY.md 8(d) "smaller actual
+                               per-posting size"); roofline.frac_canonical = the same time against 4-byte doc ids
   roofline.batch_achieved / batch_frac       the same bytes / the step's wall time / (8 TB/s x n_gpus)  
   roofline.pcie_inclusive_frac               the same bytes / the PCIe-inclusive step time
   roofline.traffic             HBM bytes per launch from the rocprofv3 PMC pass recorded in profiles/traffic.json -- only
@@ -384,8 +387,16 @@ def main():
         pipe.close()
 
     # ---- roofline of the dominant kernel (this rank's scoring kernels) --------------------------------------------
-    post_bytes = 4 + ix.value_bytes  # 4-byte doc id + the stored value
-    alg_bytes = int(df_local[qt.long()].sum().item()) * post_bytes + nq * k * 8  # sum df_t*(4+4) + k*8, this shard
+    # sum df_t * (doc id bytes + value bytes) + k * 8, with "the smaller actual per-posting size" when the
+    # stored layout is smaller than canonical: the tier-1 kernel streams the compact copy (16-bit unit-local doc ids), the
+    # tier-2 kernel the canonical blocks (32-bit doc ids).  The dominant kernel's posting size is the one used; the
+    # canonical figure (4-byte doc ids) is reported next to it.
+    n_post = int(df_local[qt.long()].sum().item())
+    tier1_dominant = prof["wave_ms"] >= prof["block_ms"]
+    doc_bytes = 2 if (tier1_dominant and ix.post16 is not None) else 4
+    post_bytes = doc_bytes + ix.value_bytes
+    alg_bytes = n_post * post_bytes + nq * k * 8
+    alg_bytes_canonical = n_post * (4 + ix.value_bytes) + nq * k * 8
     # Dominant kernel = the tier-1 wave kernel; the tier-2 block kernel's time is kept in the denominator so that no
     # posting byte is counted without its time.  Per STEP: the per-call averages times the calls one step makes.
     score_s = (prof["wave_ms"] + prof["block_ms"]) * 1e-3 * calls_per_step
@@ -439,6 +450,9 @@ def main():
                      "kernel_ms": prof["wave_ms"] * calls_per_step, "tier2_kernel_ms": prof["block_ms"] * calls_per_step,
                      "merge_kernel_ms": prof["merge_ms"] * calls_per_step,
                      "launches_timed": prof["calls"], "launches_per_step": calls_per_step,
+                     "bytes_per_posting": post_bytes,
+                     "achieved_canonical": alg_bytes_canonical / score_s / 1e9,   # the same time against 4-byte doc ids
+                     "frac_canonical": alg_bytes_canonical / score_s / 1e9 / HBM_PEAK_GBPS,
                      "algorithmic_bytes_per_launch": alg_bytes / max(calls_per_step, 1e-9),
                      "algorithmic_bytes_per_step_all_gpus": alg_total,
                      "batch_achieved": batch_achieved, "batch_frac": batch_achieved / (HBM_PEAK_GBPS * world),

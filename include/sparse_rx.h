@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 200 /* 0.2.0: blocked posting layout */
+#define SRX_VERSION 210 /* 0.2.1: blocked posting layout + compact (16-bit local doc id) copy for tier 1 */
 
 typedef enum {
     SRX_OK = 0,
@@ -61,7 +61,7 @@ typedef enum {
  * Device-resident inverted index of one doc-range shard: term-major postings in BLOCKS + a tile skip table.
  *
  * The postings of a term (ascending shard-local doc id) are cut into one run per UNIT of unit_tiles * G consecutive
- * docs (unit_tiles * G <= 65536 for the tier-1 kernel; srx_auto_unit_tiles picks it).  Every run is padded to a
+ * docs (unit_tiles * G <= 63488 for the tier-1 kernel; srx_auto_unit_tiles picks it).  Every run is padded to a
  * multiple of 4 postings with sentinels (doc -1 - 32 * (term % 64), value 0; trailing sentinel block j holds docs
  * -1 - 32 j) and stored as blocks of 4 postings, docs and values side by side:
  *     SRX_VAL_F32: [d0 d1 d2 d3 | v0 v1 v2 v3]   8 x 32-bit words
@@ -104,6 +104,10 @@ typedef struct {
                                  values >= 0.  Gives every query an exact lower bound on its k-th best score (a doc's
                                  score is at least any single contribution when all query idf are >= 0), which the
                                  kernels use as the initial top-k threshold. */
+    const int32_t *post16;    /* optional, may be NULL: the compact copy of `post` the tier-1 kernel streams (srx_build_compact:
+                                 [(n_blocks + SRX_BLOCK_PAD) * 6 words (f32 values) / 4 words (f16)], 16-bit unit-local doc ids:
+                                 6 / 4 bytes per posting instead of 8 / 6).  Without it every query is served by the tier-2
+                                 kernel from `post` (exact, slower on short queries). */
 } srx_index_desc;
 
 typedef struct srx_index srx_index;
@@ -211,6 +215,15 @@ int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, 
                      const int32_t *post_doc, const void *post_val, const int32_t *skip, const int64_t *runpad,
                      int64_t vocab, int64_t nnz, int32_t n_tiles, int32_t tile_log2, int32_t unit_tiles, int32_t *out_post,
                      int32_t *out_skip, int64_t *out_term_ptr, int64_t n_blocks, void *stream);
+
+/* Compact copy of the blocks for the tier-1 kernel (replaces nothing in the reference: a storage choice of this engine).
+ * Block b of `post` (n_blocks_total = n_blocks + SRX_BLOCK_PAD of them) becomes
+ *     SRX_VAL_F32: [l0 | l1 << 16][l2 | l3 << 16][v0 v1 v2 v3]   6 words
+ *     SRX_VAL_F16: [l0 | l1 << 16][l2 | l3 << 16][h0 h1][h2 h3]  4 words
+ * with l = doc - first doc of the doc's unit (units of unit_tiles << tile_log2 <= 63488 docs); a sentinel (doc -1 - 32 x)
+ * becomes 0xFFFF - 32 (x mod 64).  Derived data: not stored in shard files, rebuilt after a load. */
+int srx_build_compact(int32_t device, int32_t val_type, const int32_t *post, int64_t n_blocks_total, int32_t tile_log2,
+                      int32_t unit_tiles, int32_t *out_post16, void *stream);
 
 /* hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream): the copy of a batch's result rows to pinned host memory (or
  * of a query batch to the device) on a copy stream of the caller's, without going through a framework's stream guard

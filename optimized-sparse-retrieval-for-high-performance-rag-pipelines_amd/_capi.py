@@ -37,7 +37,8 @@ class IndexDesc(ctypes.Structure):
                 ("vocab", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64), ("doc_base", ctypes.c_int64),
                 ("tile_log2", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("unit_tiles", ctypes.c_int32),
                 ("reserved0", ctypes.c_int32), ("term_ptr", ctypes.c_void_p), ("post", ctypes.c_void_p),
-                ("tile_skip", ctypes.c_void_p), ("idf", ctypes.c_void_p), ("term_bound", ctypes.c_void_p)]
+                ("tile_skip", ctypes.c_void_p), ("idf", ctypes.c_void_p), ("term_bound", ctypes.c_void_p),
+                ("post16", ctypes.c_void_p)]
 
 
 class SearchOpts(ctypes.Structure):
@@ -72,6 +73,7 @@ SYMBOLS = {
     "srx_memcpy_async": (ctypes.c_int, [_VP, _VP, _I64, _VP]),
     "srx_auto_unit_tiles": (_I32, [_I64, _I64, _I64, _I32]),
     "srx_build_blocks": (ctypes.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I64, _VP]),
+    "srx_build_compact": (ctypes.c_int, [_I32, _I32, _VP, _I64, _I32, _I32, _VP, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
 }
 

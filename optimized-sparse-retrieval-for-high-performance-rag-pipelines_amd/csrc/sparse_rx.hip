@@ -463,6 +463,9 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
 // (Measured and dropped: adding with the LDS float atomic ds_add_f32 instead of read / add / write.  It is bit-identical
 // to v_add_f32 and ordered -- tools/lds_fadd_probe.hip -- and needs half the instructions, but the LDS executes it at
 // about one lane every 7 cycles: C4 went from 47 ms to 166 ms per batch.)
+// (Measured and dropped: reading the compact copy of srx_common.h here on one-tile units -- a local id IS the accumulator
+// index, one 16-byte load per fp16 block instead of 16 + 8.  C4: 21.7 -> 20.8 ms per batch for 33 % fewer bytes: the path
+// is bound by its LDS round trips, not by HBM, so the second copy's traffic saving buys little.)
 template <typename VT, bool ALIGNED>
 __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int nt, int64_t tile_base, bool has_tile, int64_t wstart,
                                       int wlen, float my_idf, float my_qw) {
@@ -883,7 +886,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     const int su_lo = (int)(((int64_t)n_super * split) / nsq);
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / nsq);
     // Tier 2 takes the whole query when tier 1 cannot serve it, otherwise only the units tier 1 flagged.
-    const bool all_units = (nt_all > W_MAXT) || (k > W1_KMAX) || ((tpu << ix.tile_log2) > (1 << W_UNIT_LOG2)) || (dbg & 8);
+    const bool all_units = tier1_cannot_serve(ix, nt_all, k, tpu, dbg);
     const unsigned *my_ovf = ovf + (int64_t)q * ovf_words;
     bool any = all_units && nt_all > 0;
     if (!all_units && nt_all > 0)
@@ -1421,6 +1424,27 @@ __global__ void srx_blocks_sentinel_kernel(int32_t *__restrict__ out_post, int64
         reinterpret_cast<VT *>(blk + 4)[i & 3] = VT(0.0f);
     }
 }
+
+// Compact copy for tier 1 (srx_common.h, CompactWords): one thread per block, 16-bit unit-local doc ids.
+template <typename VT>
+__global__ void srx_compact_blocks_kernel(const int32_t *__restrict__ post, int64_t n_blocks_total, int unit_docs,
+                                          int32_t *__restrict__ out) {
+    constexpr int BW = BlockWords<VT>::value, CW = CompactWords<VT>::value;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks_total) return;
+    const int32_t *src = post + b * BW;
+    int32_t *dst = out + b * CW;
+    unsigned l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int d = src[c];
+        l[c] = d >= 0 ? (unsigned)(d % unit_docs) : 0xFFFFu - 32u * (unsigned)(((-1 - d) >> 5) & 63);
+    }
+    dst[0] = (int32_t)(l[0] | (l[1] << 16));
+    dst[1] = (int32_t)(l[2] | (l[3] << 16));
+#pragma unroll
+    for (int c = 4; c < BW; ++c) dst[c - 2] = src[c];  // the values, unchanged
+}
 }  // namespace
 
 // ================================================================================================
@@ -1586,6 +1610,7 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     IndexView v;
     v.term_ptr = ix->d.term_ptr;
     v.post = ix->d.post;
+    v.post16 = ix->d.post16;
     v.zero_block = ix->d.n_blocks;
     v.unit_tiles = ix->d.unit_tiles;
     v.tile_skip = ix->d.tile_skip;
@@ -1822,8 +1847,8 @@ SRX_API int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, 
         return fail(SRX_ERR_INVALID, "srx_auto_unit_tiles: bad argument%s");
     // The largest unit (in tiles) for which the run of an average term inside a unit overflows the registers of its lane
     // group (8 lanes x W_R postings in the reference case of an 8-term query) with negligible probability (mean +
-    // 5 sigma, Poisson), and whose docs fit the tier-1 bitmap (65536).
-    const int max_tpu_bitmap = (1 << W_UNIT_LOG2) >> tile_log2;
+    // 5 sigma, Poisson), and whose docs fit the tier-1 bitmap / the compact copy's local ids (63488).
+    const int max_tpu_bitmap = W_UNIT_MAX_DOCS >> tile_log2;  // 16-bit unit-local ids below the sentinels' range (>= 3 tiles of 16384)
     const double per_doc_per_term = (double)nnz / ((double)n_docs * (double)vocab);
     auto fits = [&](int t) {
         const double mean = per_doc_per_term * (double)t * (double)(1ll << tile_log2);
@@ -1832,6 +1857,24 @@ SRX_API int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, 
     int tpu = 1;
     while (tpu < MAX_TPS && tpu < max_tpu_bitmap && fits(tpu + 1)) ++tpu;
     return tpu;
+}
+
+SRX_API int srx_build_compact(int32_t device, int32_t val_type, const int32_t *post, int64_t n_blocks_total, int32_t tile_log2,
+                              int32_t unit_tiles, int32_t *out_post16, void *stream_v) {
+    if (!post || !out_post16 || n_blocks_total <= 0) return fail(SRX_ERR_INVALID, "srx_build_compact: bad argument%s");
+    if (val_type != SRX_VAL_F32 && val_type != SRX_VAL_F16) return fail(SRX_ERR_INVALID, "srx_build_compact: bad val_type%s");
+    if (tile_log2 < 6 || tile_log2 > SRX_MAX_TILE_LOG2 || unit_tiles < 1 || ((int64_t)unit_tiles << tile_log2) > W_UNIT_MAX_DOCS)
+        return fail(SRX_ERR_INVALID, "srx_build_compact: a unit must cover at most 63488 docs (16-bit unit-local ids below the sentinels)%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const unsigned grid = (unsigned)((n_blocks_total + 255) / 256);
+    const int unit_docs = unit_tiles << tile_log2;
+    if (val_type == SRX_VAL_F32)
+        hipLaunchKernelGGL(srx_compact_blocks_kernel<float>, dim3(grid), dim3(256), 0, stream, post, n_blocks_total, unit_docs, out_post16);
+    else
+        hipLaunchKernelGGL(srx_compact_blocks_kernel<__half>, dim3(grid), dim3(256), 0, stream, post, n_blocks_total, unit_docs, out_post16);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
 }
 
 SRX_API int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, const int32_t *post_term,

@@ -60,6 +60,8 @@ constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thre
 constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
 constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
+constexpr int W_UNIT_MAX_DOCS = 65536 - 2048;  // ... and, for the compact tier-1 copy (16-bit unit-local doc ids), leaves the top 2048
+                                            // local ids to the sentinels (0xFFFF - 32 j, j < 64: bitmap words of their own)
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 #ifndef SRX_W_R
 #define SRX_W_R 12
@@ -114,9 +116,24 @@ struct BlockWords<__half> {
     static constexpr int value = 6;
 };
 
+// Compact copy for tier 1 (srx_build_compact): block b of `post` re-encoded with 16-bit UNIT-LOCAL doc ids,
+//     f32 values: [l0 | l1 << 16][l2 | l3 << 16][v0 v1 v2 v3]   6 words = 24 bytes  (8 -> 6 bytes per posting)
+//     f16 values: [l0 | l1 << 16][l2 | l3 << 16][h0 h1][h2 h3]  4 words = 16 bytes  (6 -> 4 bytes per posting)
+// local id = doc - unit_first_doc (units of unit_tiles << tile_log2 <= W_UNIT_MAX_DOCS docs); a sentinel (doc -1 - 32 x)
+// becomes 0xFFFF - 32 (x mod 64): above every real local id, a bitmap word of its own, value 0 as before.
+template <typename VT>
+struct CompactWords {
+    static constexpr int value = 6;
+};
+template <>
+struct CompactWords<__half> {
+    static constexpr int value = 4;
+};
+
 struct IndexView {
     const int64_t *term_ptr;   // [vocab+1] padded position of the term's first posting (a multiple of 4)
     const int32_t *post;       // the blocks
+    const int32_t *post16;     // the compact copy tier 1 streams (same block indices); nullptr: tier 2 serves every query
     const int32_t *tile_skip;  // [vocab*(n_tiles+1)] padded postings of term t before tile j, relative to term_ptr[t]
                                // (a multiple of 4 wherever j is a multiple of unit_tiles)
     const float *idf;
@@ -433,6 +450,29 @@ __device__ __forceinline__ void load_block(const int32_t *blk, __half, int (&d)[
     const srx_i2u b = gload_i2(blk + 4);
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
     const int bx = b.x, by = b.y;
+    const __half2 h0 = *reinterpret_cast<const __half2 *>(&bx), h1 = *reinterpret_cast<const __half2 *>(&by);
+    v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);
+}
+
+// The one rule both tiers apply: tier 1 (wave_kernel.hip) serves a query of nt > 0 terms iff this is false; tier 2
+// (sparse_rx.hip) then takes the whole query instead of the flagged units only.
+__device__ __forceinline__ bool tier1_cannot_serve(const IndexView &ix, int nt, int k, int tpu, int dbg) {
+    return nt > W_MAXT || k > W1_KMAX || (tpu << ix.tile_log2) > W_UNIT_MAX_DOCS || ix.post16 == nullptr || (dbg & 8) != 0;
+}
+
+// one block of the compact copy: 4 unit-local docs + 4 values
+__device__ __forceinline__ void load_block16(const int32_t *blk, float, int (&d)[4], float (&v)[4]) {
+    const srx_i2u a = gload_i2(blk);
+    const srx_i4u b = gload_i4(blk + 2);
+    d[0] = (int)((unsigned)a.x & 0xFFFFu); d[1] = (int)((unsigned)a.x >> 16);
+    d[2] = (int)((unsigned)a.y & 0xFFFFu); d[3] = (int)((unsigned)a.y >> 16);
+    v[0] = __int_as_float(b.x); v[1] = __int_as_float(b.y); v[2] = __int_as_float(b.z); v[3] = __int_as_float(b.w);
+}
+__device__ __forceinline__ void load_block16(const int32_t *blk, __half, int (&d)[4], float (&v)[4]) {
+    const srx_i4u a = gload_i4(blk);
+    d[0] = (int)((unsigned)a.x & 0xFFFFu); d[1] = (int)((unsigned)a.x >> 16);
+    d[2] = (int)((unsigned)a.y & 0xFFFFu); d[3] = (int)((unsigned)a.y >> 16);
+    const int bx = a.z, by = a.w;
     const __half2 h0 = *reinterpret_cast<const __half2 *>(&bx), h1 = *reinterpret_cast<const __half2 *>(&by);
     v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);
 }

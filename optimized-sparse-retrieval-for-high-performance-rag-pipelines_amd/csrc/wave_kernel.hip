@@ -3,8 +3,10 @@
 // Replaces simd_bm25_score + fast_topk_selection (rag_system/core/retrieval.py:41-92) / simd_tfidf_score
 // (rag_system/pipeline/evaluate_rag_pipeline.py:95-121) for queries of <= 64 terms at k <= 112 (W1_KMAX).
 //
-// Layout it relies on (srx_common.h, IndexView): a term's postings are padded runs of 32-byte blocks
-// [4 docs | 4 values], one run per unit of <= 65536 docs; padding postings are sentinels (negative doc, value 0) and idle
+// Layout it relies on (srx_common.h, IndexView): a term's postings are padded runs of blocks [4 docs | 4 values], one run
+// per unit of <= 63488 docs; tier 1 streams the COMPACT copy of the blocks (post16: 16-bit unit-local doc ids, 24 bytes per
+// block with fp32 values, 16 with fp16 -- 6 / 4 bytes per posting instead of 8 / 6: the kernel runs at the HBM ceiling, so
+// bytes are time); padding postings are sentinels (local id 0xFFFF - 32 x, above every real local id, value 0) and idle
 // loads are redirected to an all-sentinel block of the lane's own (their bitmap words differ per lane / per term: LDS
 // atomics of several lanes on one address serialise).  A posting with value 0 is a no-op by construction of every step
 // below, so the unit loop needs NO per-posting validity predicate:
@@ -12,7 +14,7 @@
 //     dwordx4: the group reads one contiguous piece of its run); always W_R / 4 steps, the next unit's loads are in
 //     flight while this unit is scored from registers (counted vmcnt waits);
 //   * pass 1: every posting ORs  bit = min(value bits, 1) << (doc & 31)  into word (doc >> 5) & 2047 of a wave-private
-//     doc bitmap (ds_or_rtn_b32; a unit's docs have distinct low 16 bits, so no rebasing is needed); a sentinel ORs 0.
+//     doc bitmap (ds_or_rtn_b32; doc = the unit-local id); a sentinel ORs 0.
 //     `old & bit` != 0 means an earlier posting matched the same doc: accumulated into one register, tested once per
 //     unit.  5 VALU + 1 LDS instruction per posting slot;
 //   * docs matched by several terms (about 1.4 per unit on the C3 workload) are resolved in registers: the doc is
@@ -80,7 +82,7 @@ __device__ __forceinline__ int lane_reg(const int (&d)[W_R], int rs, int src) {
 template <typename VT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE))) void srx_wave_kernel(const srx_wave_launch a) {
     __shared__ WaveShared2 S;
-    constexpr int BW = BlockWords<VT>::value;
+    constexpr int BW = CompactWords<VT>::value;  // tier 1 streams the compact copy (16-bit unit-local docs)
     const IndexView &ix = a.ix;
     const int lane = threadIdx.x;
     const int k = a.k;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
     const int t0 = a.q_ptr[q];
     const int nt = a.q_ptr[q + 1] - t0;
     const int tpu = ix.unit_tiles;
-    if (nt == 0 || nt > W_MAXT || k > W1_KMAX || (tpu << ix.tile_log2) > (1 << W_UNIT_LOG2) || (a.dbg & 8)) {  // tier 2 serves it
+    if (nt == 0 || tier1_cannot_serve(ix, nt, k, tpu, a.dbg)) {  // tier 2 serves it
         if (lane == 0) {
             a.cand_count[list] = 0;
             if (nt > 0) a.work[1 + atomicAdd(&a.work[0], 1)] = (int)blockIdx.x;
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         }
         unsigned tau_seen = 0xFFFFFFFFu;  // uniform: tau the screening threshold vthr was derived from
         float vthr = 0.0f;
-        const int32_t *const zblk = ix.post + (ix.zero_block + lane) * BW;  // my lane's all-sentinel block (doc -1 - 32 lane)
-        const int32_t *const tpost = ix.post + (tblk + jl) * BW;       // my lane's first block of the term
+        const int32_t *const zblk = ix.post16 + (ix.zero_block + lane) * BW;  // my lane's all-sentinel block (local id 0xFFFF - 32 lane)
+        const int32_t *const tpost = ix.post16 + (tblk + jl) * BW;       // my lane's first block of the term
 
         // unit boundary j of my term in padded POSTINGS from the term's start (#padded postings with doc < j * tpu * G; a
         // multiple of 4).  Loaded by every lane without a branch (lanes without a term read term 0's row: valid memory,
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 const bool ok = (s4 << LPT_LOG2) < rem;
                 int dd[4];
                 float vv[4];
-                load_block((ok ? p : zblk) + off, VT(), dd, vv);  // idle: sentinel block lane + s4 * LPT (SRX_BLOCK_PAD covers it)
+                load_block16((ok ? p : zblk) + off, VT(), dd, vv);  // idle: sentinel block lane + s4 * LPT (SRX_BLOCK_PAD covers it)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     d[4 * s4 + c] = dd[c];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
 
         // Score one unit from registers (the first NR of them hold postings).  false -> the unit goes to tier 2
         // (nothing emitted).
-        auto process = [&](auto nrc, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+        auto process = [&](auto nrc, int ubase, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> bool {  // d = unit-local ids, ubase = the unit's first doc
             constexpr int NR = decltype(nrc)::value;
             if (tk.count > (unsigned)(WaveShared2::LCAP - 64 - W_DUPCAP)) {  // uniform, rare: room for this unit's multi-term docs
                 tk.tau = uniu(wave_list_select(S, tk.count, k));
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 // Lanes with a flagged posting (typically one or two) are visited one after the other: fm = the lane's
                 // flagged slots; the doc of its lowest flagged slot is broadcast, every lane picks up and blanks its
                 // posting of that doc (a doc occurs at most once per term, hence at most once per lane; sentinels carry
-                // negative docs), and the contributions are added in ascending lane order = the query's term order.
+                // local ids no real posting has), and the contributions are added in ascending lane order = the query's term order.
                 unsigned fm = 0;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                     if (sum > 0.0f && b >= tk.tau && !(a.dbg & 1024)) {  // uniform; room for W_DUPCAP entries was made above
                         if (lane == 0) {
                             S.lbits[tk.count] = b;
-                            S.ldoc[tk.count] = dd;
+                            S.ldoc[tk.count] = ubase + dd;
                         }
                         ++tk.count;
                     }
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                     if (__ballot(pass) != 0ull) {
                         const float c = 0.0f + (v[r] * my_idf) * my_qw;
                         const unsigned b = __float_as_uint(c);
-                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, d[r]);
+                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, ubase + d[r]);
                     }
                 }
             }
@@ -322,23 +324,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             } else if (__ballot(lenc > 0) != 0ull) {
                 bool fine;
                 bool done = false;
+                const int ubase = (su * tpu) << ix.tile_log2;
                 if constexpr (W_R > 12) {
                     if (__ballot(lenc - jl > 3 * LPT) != 0ull) {  // uniform: the fourth load step holds postings
-                        fine = process(IntC<16>{}, d, v);
+                        fine = process(IntC<16>{}, ubase, d, v);
                         done = true;
                     }
                 }
                 if constexpr (W_R > 8) {
                     if (!done && __ballot(lenc - jl > 2 * LPT) != 0ull) {  // uniform: the third load step holds postings
-                        fine = process(IntC<12>{}, d, v);
+                        fine = process(IntC<12>{}, ubase, d, v);
                         done = true;
                     }
                 }
                 if (!done) {
                     if (__ballot(lenc - jl > LPT) != 0ull)
-                        fine = process(IntC<8>{}, d, v);
+                        fine = process(IntC<8>{}, ubase, d, v);
                     else
-                        fine = process(IntC<4>{}, d, v);
+                        fine = process(IntC<4>{}, ubase, d, v);
                 }
                 if (!fine) flag_tier2(su);
             }

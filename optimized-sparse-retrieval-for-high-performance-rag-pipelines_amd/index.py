@@ -192,6 +192,7 @@ class DeviceIndex:
         if post.dtype != torch.int32 or post.numel() < (self.n_blocks + BLOCK_PAD) * words:
             raise ValueError("post must be int32 and hold n_blocks + SRX_BLOCK_PAD blocks")
         self._h = None
+        self.post16 = self._build_compact()
         self._create_handle(term_bound)
         self._ws = None
         self._opts = _capi.SearchOpts()
@@ -200,11 +201,30 @@ class DeviceIndex:
     def value_bytes(self) -> int:
         return 4 if self.val_type == _capi.SRX_VAL_F32 else 2
 
+    UNIT_MAX_DOCS = 65536 - 2048  # W_UNIT_MAX_DOCS in csrc/srx_common.h
+
+    def _build_compact(self):
+        """The compact copy of the blocks the tier-1 kernel streams (16-bit unit-local doc ids: 6 / 4 bytes per posting
+        instead of 8 / 6; ``srx_build_compact``).  Derived data: never stored, rebuilt from ``post`` whenever an index is
+        created or loaded.  None when a unit covers more docs than 16-bit local ids allow (tier 2 then serves everything)."""
+        torch = _torch()
+        if (self.unit_tiles << self.tile_log2) > self.UNIT_MAX_DOCS:
+            return None
+        cw = 6 if self.val_type == _capi.SRX_VAL_F32 else 4
+        total = self.n_blocks + BLOCK_PAD
+        with torch.cuda.device(self.device):
+            out = torch.empty(total * cw, dtype=torch.int32, device=self.device)
+            _capi.check(_capi.lib().srx_build_compact(self.device.index or 0, self.val_type, _ptr(self.post), total, self.tile_log2,
+                                                      self.unit_tiles, _ptr(out), _stream_ptr(torch, self.device)), "srx_build_compact")
+            torch.cuda.current_stream(self.device).synchronize()
+        return out
+
     def _create_handle(self, table) -> None:
         d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
                             nnz=self.nnz, n_blocks=self.n_blocks, doc_base=self.doc_base, tile_log2=self.tile_log2,
                             n_tiles=self.n_tiles, unit_tiles=self.unit_tiles, reserved0=0, term_ptr=_ptr(self.term_ptr),
-                            post=_ptr(self.post), tile_skip=_ptr(self.tile_skip), idf=_ptr(self.idf), term_bound=_ptr(table))
+                            post=_ptr(self.post), tile_skip=_ptr(self.tile_skip), idf=_ptr(self.idf), term_bound=_ptr(table),
+                            post16=_ptr(self.post16))
         h = ctypes.c_void_p()
         _capi.check(_capi.lib().srx_index_create(ctypes.byref(d), ctypes.byref(h)), "srx_index_create")
         if self._h:

@@ -318,7 +318,7 @@ def test_blocked_layout_matches_numpy_builder(rx):
     """srx_build_tile_skip + srx_build_blocks (device index construction) against the NumPy restatement of the blocked
     layout (tests/parity.py): padded runs per unit, sentinels (doc -1, value 0), padded skip table and term offsets --
     f32 and f16 values, units of 1 / 3 / 4 tiles, docs not a multiple of the tile, empty terms."""
-    from parity import np_build_blocks
+    from parity import np_build_blocks, np_compact_blocks
     from sparse_rx import synth
     c = synth.zipf_corpus_np(7_013, 300, 20, seed=77)
     idf = np.ones(c.vocab, np.float32)
@@ -331,10 +331,24 @@ def test_blocked_layout_matches_numpy_builder(rx):
             assert np.array_equal(ix.tile_skip.cpu().numpy(), skip), (ut, vd)
             got = ix.post.cpu().numpy()
             assert got.shape == post.shape and np.array_equal(got, post), (ut, vd)
+            # the compact copy tier 1 streams (16-bit unit-local doc ids)
+            assert ix.post16 is not None
+            assert np.array_equal(ix.post16.cpu().numpy(), np_compact_blocks(post, ut << 8, npd)), (ut, vd)
             ix.close()
     auto = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", tile_log2=8)
-    assert 1 <= auto.unit_tiles <= 64 and (auto.unit_tiles << 8) <= 65536
+    assert 1 <= auto.unit_tiles <= 64 and (auto.unit_tiles << 8) <= 65536 - 2048
     auto.close()
+    # a unit of more than 63488 docs has no compact copy: tier 2 serves every query, results stay exact
+    big = synth.uniform_corpus_np(70_000, 500, 6, seed=5)
+    ixb = rx.DeviceIndex.from_csr(big.indptr, big.indices, big.data, np.ones(big.vocab, np.float32), mode="dot", tile_log2=14, unit_tiles=4)
+    assert ixb.post16 is None
+    q = synth.queries_np(16, big.vocab, 4, seed=6)
+    gd, gs, gc = ixb.search(*q, 10)
+    import oracle
+    ed, es, ec = oracle.search_batch(big.indptr, big.indices, big.data, None, np.ones(big.vocab, np.float32), q[0], q[1], q[2], 10,
+                                     mode=oracle.MODE_TFIDF_F32)
+    assert np.array_equal(gc, ec) and np.array_equal(gd, ed) and np.array_equal(gs.view(np.uint32), es.view(np.uint32))
+    ixb.close()
 
 
 def test_impacts_bit_exact(rx):
