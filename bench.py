@@ -208,6 +208,11 @@ def main():
         args.build_unit_tiles = w.get("unit_tiles", 0)
     n_docs, V, k, nq = w["n_docs"], w["vocab"], w["k"], w["n_queries"]
     want_check = not args.no_cpu_baseline          # oracle checks (and, at N = 1, the timed CPU baseline)
+    if args.emulate_world > 1 and want_check:
+        # the emulated corpus-wide bounds cut this shard's rows below its own top-k (the other shards' docs would fill
+        # them): a timing rehearsal only, nothing to compare with the oracle
+        log("[bench] --emulate-world: timing rehearsal, oracle checks and the CPU baseline are skipped")
+        want_check = False
     want_cpu = want_check and world == 1 and not args.force_dist
 
     t_build = time.perf_counter()
