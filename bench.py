@@ -361,7 +361,8 @@ def main():
     # ---- PCIe-inclusive: the same steps fed from host batches through the pinned double-buffered pipeline ----------
     pcie_qps = pcie_ms = None
     if dist is None:
-        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=args.pipe_depth, zero_copy_queries=not args.pipe_copy)
+        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=args.pipe_depth, zero_copy_queries=not args.pipe_copy,
+                                           zero_copy_results=not args.pipe_copy)
         n_p = max(20, min(2 * args.steps, 60))
         tickets = []
         for i in range(12):  # warm-up: the pinned staging / result buffers are first touched here (slow the first few times)
@@ -385,6 +386,8 @@ def main():
         if not args.debug and not (np.array_equal(pd_, rd) and np.array_equal(ps_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(pc_, rc_)):
             raise SystemExit("PARITY FAILURE: the host-batch pipeline returned rows that differ from the device-resident search")
         log(f"[bench] host pipeline: submit {1e3 * t_sub / n_p:.3f} ms/batch, result wait {1e3 * t_res / n_p:.3f} ms/batch")
+        ht = [1e3 * x / (n_p + 12) for x in pipe.host_times]
+        log(f"[bench] host pipeline: inside submit (incl. warm-up batches): validate {ht[0]:.3f}, staging {ht[1]:.3f}, search call {ht[2]:.3f}, events + D2H call {ht[3]:.3f} ms/batch")
         log(f"[bench] PCIe-inclusive (host query batch in, host results out, pinned, {args.pipe_depth} slots): {pcie_qps:,.0f} queries/s "
             f"({pcie_ms:.3f} ms/step vs {1e3 * elapsed / args.steps:.3f} device-resident)")
         pp = ix.profile_read()

@@ -644,7 +644,7 @@ def test_host_batch_pipeline(rx):
     k = 100
     batches = [synth.queries_np(n, c.vocab, t, seed=40 + i) for i, (n, t) in enumerate([(200, 8), (1, 3), (137, 12), (200, 8), (64, 1), (199, 5)])]
     for zero_copy in (False, True):  # explicit H2D copy of the query CSR / kernels reading the pinned buffer in place
-        p2 = rx.HostBatchPipeline(ix, 200, 200 * 12, k, depth=3, zero_copy_queries=zero_copy)
+        p2 = rx.HostBatchPipeline(ix, 200, 200 * 12, k, depth=3, zero_copy_queries=zero_copy, zero_copy_results=zero_copy)
         tk2 = [p2.submit(*b) for b in batches[:3]]
         for b, t in zip(batches[:3], tk2):
             _assert_exact(tuple(x.copy() for x in p2.result(t)), _oracle_batch(c, idf, avgdl, b, k), f"pipeline zero_copy={zero_copy}")
