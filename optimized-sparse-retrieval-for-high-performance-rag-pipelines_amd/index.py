@@ -299,6 +299,29 @@ class DeviceIndex:
                 post_doc = rows[perm].contiguous()
                 tf = vals[perm].contiguous()
                 del perm
+                # Duplicate (doc, term) entries: SciPy sums them when the reference assembles its CSR
+                # (csr_matrix((data, (rows, cols))), retrieval.py:171-175); here they are adjacent after the stable
+                # sort (rows ascend inside a term) and are summed the same way, in input order.  The kernels rely on
+                # one posting per (doc, term).
+                if nnz > 1:
+                    dup = (cols_sorted[1:] == cols_sorted[:-1]) & (post_doc[1:] == post_doc[:-1])
+                    if bool(dup.any().item()):
+                        first = torch.ones(nnz, dtype=torch.bool, device=dev)
+                        first[1:] = ~dup
+                        gid = torch.cumsum(first.to(torch.int64), 0) - 1
+                        ar = torch.arange(nnz, device=dev, dtype=torch.int64)
+                        pos = ar - torch.cummax(torch.where(first, ar, torch.zeros_like(ar)), 0).values  # rank inside its group
+                        merged = tf[first].clone()
+                        for j in range(1, int(pos.max().item()) + 1):  # one add per group and step: deterministic, input order
+                            m = pos == j
+                            merged[gid[m]] += tf[m]
+                        tf = merged
+                        del ar, pos, merged
+                        cols_sorted, post_doc = cols_sorted[first].contiguous(), post_doc[first].contiguous()
+                        nnz = cols_sorted.numel()
+                        df = torch.bincount(cols_sorted, minlength=V)
+                        del first, gid
+                    del dup
             else:
                 post_doc = torch.zeros(0, dtype=torch.int32, device=dev)
                 tf = torch.zeros(0, dtype=torch.float32, device=dev)

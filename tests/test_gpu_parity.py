@@ -712,3 +712,35 @@ def test_sharded_searcher_overlap_on_one_gpu(rx):
         ix.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_duplicate_postings_are_summed_like_scipy(rx):
+    """A CSR that lists the same (doc, term) twice or three times: SciPy sums duplicates when the reference assembles its
+    matrix (retrieval.py:171-175); the device builder merges them the same way, so the search equals the oracle on the
+    canonical (summed) CSR."""
+    import oracle
+    from scipy.sparse import csr_matrix
+    from sparse_rx import synth
+    rng = np.random.default_rng(9)
+    n_docs, V = 3_000, 400
+    rows = rng.integers(0, n_docs, 60_000)
+    cols = (rng.zipf(1.3, 60_000) - 1) % V          # hot terms: many repeated (doc, term) pairs
+    vals = rng.integers(1, 4, 60_000).astype(np.float32)
+    o = np.lexsort((np.arange(len(rows)), rows))     # row-major input order, duplicates NOT adjacent inside a row
+    rows, cols, vals = rows[o], cols[o], vals[o]
+    indptr = np.zeros(n_docs + 1, np.int64)
+    indptr[1:] = np.cumsum(np.bincount(rows, minlength=n_docs))
+    m = csr_matrix((vals, (rows, cols)), shape=(n_docs, V), dtype=np.float32)  # sums duplicates
+    m.sort_indices()
+    assert m.nnz < len(vals)
+    dl = np.asarray(m.sum(axis=1)).ravel().astype(np.float32)
+    df = np.bincount(m.indices, minlength=V)
+    idf = np.log((n_docs - df + 0.5) / (df + 0.5)).astype(np.float32)
+    avgdl = float(np.mean(dl))
+    ix = rx.DeviceIndex.from_csr(indptr, cols.astype(np.int32), vals, idf, doc_lengths=dl, avgdl=avgdl, tile_log2=8)
+    assert ix.nnz == m.nnz
+    q = synth.queries_np(64, V, 6, seed=3, dist="zipf", s=1.0)
+    gd, gs, gc = ix.search(*q, 20)
+    ed, es, ec = oracle.search_batch(m.indptr, m.indices, m.data, dl, idf, q[0], q[1], q[2], 20, 1.2, 0.75, avgdl)
+    assert np.array_equal(gc, ec) and np.array_equal(gd, ed) and np.array_equal(gs.view(np.uint32), es.view(np.uint32))
+    ix.close()
