@@ -395,6 +395,47 @@ def test_larger_properties(rx):
     ix.close()
 
 
+def test_c3_full_size_properties(rx):
+    """BASELINE config C3 at FULL size (10 M docs x 100 k vocab, 10^9 postings, 10 k queries x 8 terms, k = 100), corpus
+    generated on the device like bench.py does.  The oracle's full-CSR scan is bench.py's job at this size (it checks a
+    sample of every run); here the size-independent properties: canonical order, doc-unique rows, k-prefix property,
+    idempotence, and -- the strong one -- every query of a 96-query sub-batch returns bit-identical rows when searched
+    alone (64 doc-range splits + tier-2 lists + merge kernel) and inside the 10 k batch (unsplit, ranked by tier 1)."""
+    import torch
+    from sparse_rx import synth
+    dev = torch.device("cuda:0")
+    n_docs, V, nnz_per_doc, seed, nq, k = 10_000_000, 100_000, 100, 20253, 10_000, 100
+    rows_l, cols_l, tf_l, dl_l = [], [], [], []
+    for ci in range(n_docs // synth.CHUNK_DOCS):
+        r, cc, tf, dl = synth.uniform_chunk_torch(ci, synth.CHUNK_DOCS, V, nnz_per_doc, seed, dev)
+        rows_l.append(r + ci * synth.CHUNK_DOCS); cols_l.append(cc); tf_l.append(tf); dl_l.append(dl)
+    rows, cols, tf, dl = torch.cat(rows_l), torch.cat(cols_l), torch.cat(tf_l), torch.cat(dl_l)
+    del rows_l, cols_l, tf_l, dl_l
+    df = torch.bincount(cols, minlength=V).cpu().numpy()
+    idf = torch.as_tensor(np.log((n_docs - df + 0.5) / (df + 0.5)).astype(np.float32), device=dev)
+    avgdl = float(np.mean(dl.cpu().numpy()))
+    ix = rx.DeviceIndex.from_coo(rows, cols, tf, idf, n_docs, doc_lengths=dl, avgdl=avgdl, device=dev, tile_log2=14)
+    del rows, cols, tf
+    assert ix.post16 is not None and ix.nnz > 990_000_000
+    q = synth.queries_np(nq, V, 8, seed=seed + 1)
+    d, s, n = ix.search(*q, k)
+    assert np.all(n == k)                                        # ~80 k matching docs per query
+    assert np.all(d >= 0) and np.all(d < n_docs) and np.all(s > 0)
+    assert np.all((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (d[:, :-1] < d[:, 1:])))  # (score desc, doc asc), doc-unique
+    d2, s2, n2 = ix.search(*q, k)
+    assert np.array_equal(d, d2) and np.array_equal(s.view(np.uint32), s2.view(np.uint32)) and np.array_equal(n, n2)
+    d10, s10, n10 = ix.search(*q, 10)
+    assert np.array_equal(d10, d[:, :10]) and np.array_equal(s10.view(np.uint32), s[:, :10].view(np.uint32))
+    lo, hi = 5000, 5096                                          # a sub-batch: other work-item plan (splits + merge)
+    qs = ((q[0][lo: hi + 1] - q[0][lo]).astype(np.int32), q[1][q[0][lo]: q[0][hi]], q[2][q[0][lo]: q[0][hi]])
+    ds, ss, ns = ix.search(*qs, k)
+    assert np.array_equal(ds, d[lo:hi]) and np.array_equal(ss.view(np.uint32), s[lo:hi].view(np.uint32)) and np.array_equal(ns, n[lo:hi])
+    ix.set_opts(debug=8)                                         # the same sub-batch through the tier-2 kernel alone
+    dt, st, nt_ = ix.search(*qs, k)
+    assert np.array_equal(dt, ds) and np.array_equal(st.view(np.uint32), ss.view(np.uint32)) and np.array_equal(nt_, ns)
+    ix.close()
+
+
 def test_registry_twin_golden(rx, golden_dir, tmp_path):
     """OptimizedBM25Retriever / RetrieverRegistry / OptimizedRetriever against results the reference's registry twin
     produced on the same corpus (tests/golden/registry_small.json): bm25, bm25_custom (k1=1.6, b=0.8), tfidf."""
