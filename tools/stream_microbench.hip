@@ -11,6 +11,7 @@
 //      adjacent, a lane group reads 256 contiguous bytes per step
 //   3  as 2 with 6-byte postings: [4 x u16 docs (8 B) | 4 x f32 (16 B)] = 24-byte blocks (dwordx2 + dwordx4)
 //   4  as 2, prefetch distance 2 units (three register sets)
+//   5  as 3 with the 24-byte blocks stored in 48-byte pairs [docs A | docs B][values A][values B] (aligned dwordx4)
 // Reports useful bytes / time.  usage: stream_microbench [n_queries] [lds_bytes_per_wave]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -60,6 +61,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k(
                 const uint64_t w0 = ok ? ((p + eo) >> 2) * 6 : (uint64_t)(eo >> 2) * 6;  // 24-byte blocks = 6 dwords
                 const P2 a = *reinterpret_cast<const P2 *>(A + w0);
                 const P4 b = *reinterpret_cast<const P4 *>(A + w0 + 2);
+                d[4 * s] = a.x & 0xFFFF; d[4 * s + 1] = a.x >> 16; d[4 * s + 2] = a.y & 0xFFFF; d[4 * s + 3] = a.y >> 16;
+                v[4 * s] = b.x; v[4 * s + 1] = b.y; v[4 * s + 2] = b.z; v[4 * s + 3] = b.w;
+            } else if (VAR == 5) {
+                // 24-byte blocks stored as PAIRS of 48 bytes: [docs A (8 B) | docs B (8 B)][values A (16 B)][values B (16 B)]:
+                // every dwordx4 is 16-byte aligned, every dwordx2 8-byte aligned, for any block index
+                const uint64_t blk = ok ? ((p + eo) >> 2) : (uint64_t)(eo >> 2);
+                const uint64_t w0 = (blk >> 1) * 12 + (blk & 1) * 2;
+                const P2 a = *reinterpret_cast<const P2 *>(A + w0);
+                const P4 b = *reinterpret_cast<const P4 *>(A + w0 + 4 + (blk & 1) * 2);
                 d[4 * s] = a.x & 0xFFFF; d[4 * s + 1] = a.x >> 16; d[4 * s + 2] = a.y & 0xFFFF; d[4 * s + 3] = a.y >> 16;
                 v[4 * s] = b.x; v[4 * s + 1] = b.y; v[4 * s + 2] = b.z; v[4 * s + 3] = b.w;
             } else {
@@ -148,5 +158,6 @@ int main(int argc, char **argv) {
     run(2, k<2>, 8.0);
     run(3, k<3>, 6.0);
     run(4, k<4>, 8.0);
+    run(5, k<5>, 6.0);
     return 0;
 }
