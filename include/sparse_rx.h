@@ -202,7 +202,8 @@ int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *
                         int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
 
 /* Tiles per unit for a corpus of this density: the largest unit whose average per-term run still fits the tier-1
- * kernel's registers with a 5-sigma margin and whose docs fit its 65536-bit bitmap.  Host-only, returns the value. */
+ * kernel's registers with a 5-sigma margin and whose docs fit the 16-bit local ids of the compact copy (<= 63488).  Host-only,
+ * returns the value. */
 int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, int32_t tile_log2);
 
 /* Plain term-major arrays -> the blocked layout of srx_index_desc.  Inputs: term_ptr i64[vocab+1], post_term i32[nnz]

@@ -8,7 +8,7 @@
 //   fast_topk_selection  rag_system/core/retrieval.py:79-92      (+ score>0 filter :292-296)
 //
 // Design: the index is term-major with a tile skip table; a term's postings are stored as blocks of 4
-// (docs and values side by side), one padded run per unit of <= 65536 docs.  A query's doc range is cut into those
+// (docs and values side by side), one padded run per unit of <= 63488 docs.  A query's doc range is cut into those
 // units.  Two tiers score them, a merge kernel ranks:
 //   tier 1  srx_wave_kernel   (wave_kernel.hip) ONE WAVEFRONT per (query, split), no barriers; flags what it cannot
 //           serve (long runs, many multi-term docs, > 64 terms, k > 128) for tier 2.

@@ -59,8 +59,8 @@ constexpr int MAX_TPS = 64;                 // tiles per supertile handled by th
 constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thread (4096 per workgroup)
 constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
-constexpr int W_UNIT_LOG2 = 16;             // a unit covers <= 65536 docs: 1 bit per doc in a wave-private LDS bitmap
-constexpr int W_UNIT_MAX_DOCS = 65536 - 2048;  // ... and, for the compact tier-1 copy (16-bit unit-local doc ids), leaves the top 2048
+constexpr int W_UNIT_LOG2 = 16;             // the wave-private LDS bitmap has 65536 bits: 1 per unit-local doc id
+constexpr int W_UNIT_MAX_DOCS = 65536 - 2048;  // a unit covers <= 63488 docs: the compact tier-1 copy (16-bit unit-local doc ids) leaves the top 2048
                                             // local ids to the sentinels (0xFFFF - 32 j, j < 64: bitmap words of their own)
 constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
 #ifndef SRX_W_R
@@ -98,7 +98,7 @@ __host__ __device__ inline int bound_column(int k) { return k <= 1 ? 0 : k <= 10
 }  // namespace
 
 // Posting storage (layout v2, "blocked"): the postings of a term are cut into runs, one per UNIT of
-// unit_tiles * 2^tile_log2 <= 65536 consecutive docs; every run is padded to a multiple of 4 postings with sentinels
+// unit_tiles * 2^tile_log2 <= 63488 consecutive docs; every run is padded to a multiple of 4 postings with sentinels
 // (negative doc, value 0) and stored as blocks of 4 postings, docs and values of a block side by side:
 //     f32 values: [d0 d1 d2 d3 | v0 v1 v2 v3]           8 words = 32 bytes
 //     f16 values: [d0 d1 d2 d3 | h0 h1 | h2 h3]          6 words = 24 bytes
