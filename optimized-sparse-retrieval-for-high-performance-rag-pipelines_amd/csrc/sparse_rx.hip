@@ -957,14 +957,17 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
         // one-tile units + finite weights: the unmasked form (see wave_dense_accumulate)
         const bool wd_aligned = ix.unit_tiles == 1 && !nonfinite && !(dbg & 4096);
         auto dense_quads = [&](int ja, int jb) {  // tiles [ja, jb): four at a time, one per wave, no block barriers inside
+            // my term's run boundaries of the NEXT group's tile are loaded while this group is accumulated (a dependent
+            // load at the top of every group exposed one memory round trip per four tiles); clamped index, no branch
+            const int jlast = ix.n_tiles - 1;
+            int a_n = gload_i32(wskip + min(ja + (tid >> 6), jlast)), b_n = gload_i32(wskip + min(ja + (tid >> 6), jlast) + 1);
             for (int j0 = ja; j0 < jb; j0 += WAVES) {
                 const int j = j0 + (tid >> 6);
                 const bool has_tile = j < jb;
-                int a = 0, b = 0;
-                if (has_tile && (tid & 63) < nt) {
-                    a = gload_i32(wskip + j);
-                    b = gload_i32(wskip + j + 1);
-                }
+                const bool mine = has_tile && (tid & 63) < nt;
+                const int a = mine ? a_n : 0, b = mine ? b_n : 0;
+                a_n = gload_i32(wskip + min(j + WAVES, jlast));
+                b_n = gload_i32(wskip + min(j + WAVES, jlast) + 1);
                 T2(0);
                 if (wd_aligned)
                     wave_dense_accumulate<VT, true>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
