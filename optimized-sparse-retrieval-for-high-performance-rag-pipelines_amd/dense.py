@@ -218,15 +218,24 @@ class DenseF32Index:
             raise _capi.SparseRxUnavailable("no HIP device visible: DenseF32Index needs a GPU (there is no CPU fallback)")
         _capi.lib()
         self.device = torch.device(device)
-        e = embeddings if isinstance(embeddings, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(embeddings, dtype=np.float32))
-        assert e.dtype == torch.float32 and e.dim() == 2
+        e = embeddings
+        assert len(e.shape) == 2 and (not isinstance(e, torch.Tensor) or e.dtype == torch.float32)
         self.n_docs, self.dim = int(e.shape[0]), int(e.shape[1])
         self.dim_pad = (self.dim + 63) // 64 * 64
         if self.dim_pad > 1024:
             raise ValueError(f"embedding dim {self.dim} > 1024 is not supported by the f32 engine")
         with torch.cuda.device(self.device):
             self.emb = torch.zeros((self.n_docs, self.dim_pad), dtype=torch.float32, device=self.device)
-            self.emb[:, : self.dim] = e.to(self.device)
+            if isinstance(e, torch.Tensor):
+                self.emb[:, : self.dim] = e.to(self.device)
+            else:
+                # host array, possibly a read-only memory map of embedding_path (retrieval.py:329-335): streamed to the device
+                # in chunks of <= 64 MB (np.array copies a chunk: a whole-file host copy is never made, and the map itself is
+                # never wrapped in a tensor)
+                rows = max(1, (64 << 20) // max(1, 4 * self.dim))
+                for lo in range(0, self.n_docs, rows):
+                    chunk = np.array(e[lo: lo + rows], dtype=np.float32)
+                    self.emb[lo: lo + chunk.shape[0], : self.dim] = torch.from_numpy(chunk).to(self.device)
         self.doc_base = int(doc_base)
         self._ws = None
 
