@@ -73,6 +73,7 @@ def _cpu_share() -> int:
 # node the cores are divided between them.  SRX_CPU_THREADS overrides.
 _WORLD = int(os.environ.get("WORLD_SIZE", "1"))
 CPU_THREADS = int(os.environ.get("SRX_CPU_THREADS", "0")) or max(1, _cpu_share() // max(1, _WORLD))
+_OMP_PRESET = "OMP_NUM_THREADS" in os.environ
 os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 
 import numpy as np  # noqa: E402
@@ -144,6 +145,31 @@ def sharded_sample_check(dist_mod, rank, world, host_csr, doc_base, idf_np, avgd
     return bool(ok), n
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...  bench.py <same argv>`)
+    and return their exit code.  This parent never touches the GPU (no HIP call, no torch.cuda.is_available(): only the
+    device count, which does not initialise the runtime) and never re-execs; rank 0's JSON line goes to the inherited
+    stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        log(f"[bench] --gpus {n_gpus} but only {have} device(s) visible")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    if not _OMP_PRESET:
+        env.pop("OMP_NUM_THREADS", None)  # each rank sizes its own CPU share from WORLD_SIZE
+    log("[bench] self-launch: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,14 +198,16 @@ def main():
     ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="dev: take the launcher path (child ranks under torch.distributed.run) even at --gpus 1")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = None
     if world > 1 or args.force_dist:

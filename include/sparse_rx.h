@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 210 /* 0.2.1: blocked posting layout + compact (16-bit local doc id) copy for tier 1 */
+#define SRX_VERSION 300 /* 0.3.0: + srx_search_after (ranking of any depth) */
 
 typedef enum {
     SRX_OK = 0,
@@ -187,6 +187,21 @@ int srx_search_packed(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term
                       int32_t k, int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream);
 int srx_merge_topk_packed_out(int32_t device, const int32_t *packed, int32_t nq, int32_t n_lists, int32_t k,
                               int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * "Search after": the same search restricted to the docs ranked strictly AFTER a given row in the result order
+ * (score descending, doc ascending): query q only collects docs with score < after_score[q], or score == after_score[q]
+ * and global doc id > after_doc[q].  Feeding a pass the last row of the previous one pages through a ranking of any
+ * depth, which is how the host side serves top_k > SRX_MAX_K and the reference's "k >= n_docs: rank everything" branch
+ * (rag_system/core/retrieval.py:272-284; twin retriever_registry.py:304).  after_score[q] <= 0 returns nothing for q.
+ * Served by the tier-2 kernel (the tier-1 kernel and the term_bound thresholds assume an unrestricted top-k).
+ */
+int srx_search_after(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                     int32_t k, const int32_t *after_doc, const float *after_score, int32_t *out_doc, float *out_score,
+                     int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream);
+int srx_search_after_packed(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                            int32_t k, const int32_t *after_doc, const float *after_score, int32_t *out_packed,
+                            void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- device-side index construction helpers ------------------------------------------------------ */
 

@@ -58,6 +58,8 @@ SYMBOLS = {
     "srx_index_set_opts": (ctypes.c_int, [_VP, ctypes.POINTER(SearchOpts)]),
     "srx_search_workspace_bytes": (_I64, [_VP, _I32, _I32]),
     "srx_search": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_search_after": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_search_after_packed": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_merge_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "srx_merge_topk": (ctypes.c_int, [_I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_merge_topk_packed": (ctypes.c_int, [_I32, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I64, _VP]),

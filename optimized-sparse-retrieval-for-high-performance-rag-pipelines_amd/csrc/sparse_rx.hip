@@ -70,10 +70,17 @@ struct ScoreShared {
     int ptile[MAX_TPS + 1];  // overflow packer: postings per tile / group boundaries
     int grp[MAX_TPS + 1];
     int n_grp;
+    unsigned ub_bits;  // srx_search_after: only candidates ranked strictly AFTER (ub_bits, ub_doc) in (score desc, doc asc)
+    int ub_doc;        // order are collected; ub_bits = 0xFFFFFFFF: no bound (every score's bit pattern is below it)
 #ifdef SRX_T2_PAD_WORDS
     int occupancy_pad[SRX_T2_PAD_WORDS];  // dev experiment: more LDS per workgroup = fewer workgroups per CU
 #endif
 };
+
+// srx_search_after's exclusive upper bound on (score bits, shard-local doc): true when the candidate ranks after it
+__device__ __forceinline__ bool after_bound(const ScoreShared &S, unsigned b, int doc) {
+    return b < S.ub_bits || (b == S.ub_bits && doc > S.ub_doc);
+}
 
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
 // scores into the running top-k.  nt = terms in this pass.
@@ -153,7 +160,7 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned b = __float_as_uint(vs[c]);
-            const bool ok = ks[c] != EMPTY_KEY && vs[c] > 0.0f && b >= tau;
+            const bool ok = ks[c] != EMPTY_KEY && vs[c] > 0.0f && b >= tau && after_bound(S, b, ks[c]);
             ubits[j * 4 + c] = ok ? b : 0u;
             udoc[j * 4 + c] = ks[c];
         }
@@ -356,7 +363,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
                 } else {
                     const float sc = 0.0f + c;
                     const unsigned b = __float_as_uint(sc);
-                    if (sc > 0.0f && b >= tau) {
+                    if (sc > 0.0f && b >= tau && after_bound(S, b, tile_base + d)) {
                         ubits[n] = b;
                         udoc[n] = tile_base + d;
                     }
@@ -440,7 +447,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
                 last = best;
             }
             const unsigned bb = __float_as_uint(sum);
-            if (sum > 0.0f && bb >= tau) {
+            if (sum > 0.0f && bb >= tau && after_bound(S, bb, tile_base + (so_key[a] >> 8))) {
                 mbits[j] = bb;
                 mdoc[j] = tile_base + (so_key[a] >> 8);
             }
@@ -707,7 +714,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
                 unsigned tot = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now;
+                    ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now && after_bound(S, __float_as_uint(a[c]), tile_base + 4 * i + c);
                     m[c] = __ballot(ok[c]);
                     tot += (unsigned)__popcll(m[c]);
                 }
@@ -773,7 +780,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
     auto cand_key = [&](int o) -> unsigned {  // key of accumulator o: its score bits when it can enter the list, else 0
         const float x = acc[o];
         const unsigned b = __float_as_uint(x);
-        return (x > 0.0f && b >= tau) ? b : 0u;
+        return (x > 0.0f && b >= tau && after_bound(S, b, tile_base + o)) ? b : 0u;
     };
     unsigned mine = 0, lmx = 0, lmn = 0xFFFFFFFFu;
     for (int o = tid; o < n_valid; o += THREADS) {
@@ -873,7 +880,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                             const int32_t *__restrict__ q_term, const float *__restrict__ q_weight, int nq, int k,
                             int n_splits, int n_whole, int tpu, int n_super, int dbg, const unsigned *__restrict__ ovf,
                             int ovf_words, int lists_per_q, int32_t *__restrict__ cand_doc,
-                            float *__restrict__ cand_score, int32_t *__restrict__ cand_count) {
+                            float *__restrict__ cand_score, int32_t *__restrict__ cand_count,
+                            const int32_t *__restrict__ after_doc, const float *__restrict__ after_score, int64_t doc_base) {
     const int tid = threadIdx.x;
     T2_T0();
     int q, split, nsq;
@@ -918,12 +926,19 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
             }
         }
         const SumMaxMin r = block_sum_max_min(negf, t0b, 0u, S.tk.red);  // sum: low half = #negative, high half = #non-finite
-        tau0 = r.sum ? 0u : r.mx;
+        tau0 = (r.sum || after_score != nullptr) ? 0u : r.mx;  // the bounds speak of the k best of ALL docs, not of those after a row
         nonfinite = r.sum >= 0x10000u;
     }
     if (tid == 0) {
         S.tk.count = 0;
         S.tk.tau = tau0;
+        S.ub_bits = 0xFFFFFFFFu;
+        S.ub_doc = 0;
+        if (after_score != nullptr) {  // rows come back as GLOBAL ids: the bound is compared in shard-local ids
+            const int64_t d = (int64_t)after_doc[q] - doc_base;
+            S.ub_bits = __float_as_uint(fmaxf(after_score[q], 0.0f));
+            S.ub_doc = d < -1 ? -1 : d > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)d;
+        }
     }
     for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;
     __syncthreads();
@@ -1143,13 +1158,15 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
                                                                int lists_per_q, const int *__restrict__ work,
                                                                int32_t *__restrict__ cand_doc,
                                                                float *__restrict__ cand_score,
-                                                               int32_t *__restrict__ cand_count) {
+                                                               int32_t *__restrict__ cand_count,
+                                                               const int32_t *__restrict__ after_doc,
+                                                               const float *__restrict__ after_score, int64_t doc_base) {
     __shared__ ScoreShared S;
     const int n_work = work[0];
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // the previous block's LDS state is dead
         score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
-                        ovf_words, lists_per_q, cand_doc, cand_score, cand_count);
+                        ovf_words, lists_per_q, cand_doc, cand_score, cand_count, after_doc, after_score, doc_base);
     }
 }
 
@@ -1591,8 +1608,10 @@ SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int3
 namespace {
 int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
                 int32_t k, int32_t *out_doc, float *out_score, int32_t *out_count, int64_t ors, int64_t ocs,
-                void *workspace, int64_t workspace_bytes, void *stream_v) {
+                void *workspace, int64_t workspace_bytes, void *stream_v, const int32_t *after_doc = nullptr,
+                const float *after_score = nullptr) {
     if (!ix) return fail(SRX_ERR_INVALID, "srx_search: null index%s");
+    if ((after_doc == nullptr) != (after_score == nullptr)) return fail(SRX_ERR_INVALID, "srx_search_after: after_doc and after_score go together%s");
     if (nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search: need nq >= 0 and 1 <= k <= 1024%s");
     if (nq == 0) return SRX_OK;
     if (!q_ptr || !out_doc || !out_score || !out_count) return fail(SRX_ERR_INVALID, "srx_search: null query / output pointer%s");
@@ -1618,12 +1637,12 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     v.unit_tiles = ix->d.unit_tiles;
     v.tile_skip = ix->d.tile_skip;
     v.idf = ix->d.idf;
-    v.term_bound = (ix->opts.reserved & 16) ? nullptr : ix->d.term_bound;  // debug bit 16: ignore the score bounds
+    v.term_bound = ((ix->opts.reserved & 16) || after_score) ? nullptr : ix->d.term_bound;  // debug bit 16: ignore the score bounds
     v.n_docs = ix->d.n_docs;
     v.vocab = ix->d.vocab;
     v.tile_log2 = ix->d.tile_log2;
     v.n_tiles = ix->d.n_tiles;
-    const int dbg = ix->opts.reserved;
+    const int dbg = ix->opts.reserved | (after_score ? 8 : 0);  // search-after: the tier-2 kernel applies the bound, it takes every query
 
     const bool prof = ix->opts.profile != 0;
     hipEvent_t *ev = nullptr;
@@ -1658,11 +1677,11 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_score_kernel<float>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
                            q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0), ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count);
+                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base);
     else
         hipLaunchKernelGGL(srx_score_kernel<__half>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
                            q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0), ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count);
+                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     if (k <= W_KMAX && (int64_t)p.lists_per_q * k <= MW_CAP && p.lists_per_q <= 256 && !(dbg & 256))
@@ -1697,6 +1716,23 @@ SRX_API int srx_search_packed(srx_index *ix, const int32_t *q_ptr, const int32_t
     const int64_t row = 2 * (int64_t)k + 1;  // [k doc ids][k score bit patterns][count]
     return search_impl(ix, q_ptr, q_term, q_weight, nq, k, out_packed, reinterpret_cast<float *>(out_packed + k),
                        out_packed + 2 * k, row, row, workspace, workspace_bytes, stream_v);
+}
+
+SRX_API int srx_search_after(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight, int32_t nq,
+                             int32_t k, const int32_t *after_doc, const float *after_score, int32_t *out_doc, float *out_score,
+                             int32_t *out_count, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (!after_doc || !after_score) return fail(SRX_ERR_INVALID, "srx_search_after: null bound arrays%s");
+    return search_impl(ix, q_ptr, q_term, q_weight, nq, k, out_doc, out_score, out_count, (int64_t)k, (int64_t)1, workspace,
+                       workspace_bytes, stream_v, after_doc, after_score);
+}
+
+SRX_API int srx_search_after_packed(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, const float *q_weight,
+                                    int32_t nq, int32_t k, const int32_t *after_doc, const float *after_score,
+                                    int32_t *out_packed, void *workspace, int64_t workspace_bytes, void *stream_v) {
+    if (!out_packed || k <= 0 || !after_doc || !after_score) return fail(SRX_ERR_INVALID, "srx_search_after_packed: bad argument%s");
+    const int64_t row = 2 * (int64_t)k + 1;
+    return search_impl(ix, q_ptr, q_term, q_weight, nq, k, out_packed, reinterpret_cast<float *>(out_packed + k),
+                       out_packed + 2 * k, row, row, workspace, workspace_bytes, stream_v, after_doc, after_score);
 }
 
 SRX_API int srx_profile_read(srx_index *ix, float *h_ms4) {

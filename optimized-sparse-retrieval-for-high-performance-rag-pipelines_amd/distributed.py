@@ -83,6 +83,75 @@ def bm25_idf_from_df(df_global, n_docs_total: int) -> np.ndarray:
     return np.log((n_docs_total - df + 0.5) / (df + 0.5)).astype(np.float32)
 
 
+def build_sharded_host_index(corpus, idf_kind: str = "bm25", group=None):
+    """``build_bm25_index`` (retrieval.py:129-201) under torch.distributed: every rank is handed the SAME corpus dict (the
+    reference's API) and does the tokenising / counting of ITS doc range only; the corpus-wide pieces come from three
+    small collectives, so that every array equals the matching slice of the single-process index bit for bit:
+
+      * vocabulary -- the ranks' local word sets are all-gathered (objects) and united; ``sorted`` gives the same
+        code-point order and therefore the same term ids on every rank (:155);
+      * df -> idf  -- all-reduce of the local document frequencies, then the reference's f64 ``log`` (:187-189);
+      * avgdl      -- all-gather of the f32 doc lengths in doc order, ``np.mean`` on the host (:190).
+
+    Returns (HostIndex of the local rows [a, b) with GLOBAL term ids / idf / avgdl / vocabulary and ALL doc ids,
+    a, n_docs_total, doc_lengths of the whole corpus)."""
+    from collections import Counter
+
+    import torch
+    import torch.distributed as dist
+    from scipy.sparse import csr_matrix
+
+    from .index import HostIndex, bm25_idf, tfidf_idf, tokenize
+    if not corpus:
+        raise ValueError("Empty corpus provided")  # retrieval.py:133-134
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    doc_ids = list(corpus.keys())  # dict order = row order, identical on every rank
+    n_total = len(doc_ids)
+    if n_total < world:
+        raise ValueError(f"{n_total} docs cannot be sharded over {world} ranks (every shard needs at least one doc)")
+    a, b = shard_range(n_total, world, rank)
+    doc_tokens = []
+    local_vocab = set()
+    for doc_id in doc_ids[a:b]:
+        doc = corpus[doc_id]
+        text = doc.get("text", doc.get("content", doc.get("body", "")))  # :145
+        toks = tokenize(text) if text else []
+        doc_tokens.append(toks)
+        local_vocab.update(toks)
+    parts = [None] * world
+    dist.all_gather_object(parts, sorted(local_vocab), group=group)
+    vocabulary = {t: i for i, t in enumerate(sorted(set().union(*parts)))}  # :155
+    V = len(vocabulary)
+    doc_lengths = np.zeros(b - a, dtype=np.float32)
+    rows, cols, data = [], [], []
+    for i, toks in enumerate(doc_tokens):
+        doc_lengths[i] = len(toks)  # :165
+        for term, cnt in Counter(toks).items():
+            rows.append(i)
+            cols.append(vocabulary[term])
+            data.append(float(cnt))
+    m = csr_matrix((data, (rows, cols)), shape=(b - a, max(V, 1)), dtype=np.float32)  # :176-180 on the local rows
+    m.sort_indices()
+    m.eliminate_zeros()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    df = torch.as_tensor(np.bincount(m.indices, minlength=max(V, 1)).astype(np.int64), device=dev)
+    global_df(df, group)
+    df = df.cpu().numpy()
+    idf = bm25_idf(df, n_total) if idf_kind == "bm25" else tfidf_idf(df, n_total)
+    sizes = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
+    mx = max(sizes)
+    mine = torch.zeros(mx, dtype=torch.float32, device=dev)
+    mine[: b - a] = torch.as_tensor(doc_lengths, device=dev)
+    allv = torch.empty(world * mx, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(allv, mine, group=group)
+    allv = allv.cpu().numpy()
+    dl_all = np.concatenate([allv[r * mx: r * mx + sizes[r]] for r in range(world)]).astype(np.float32)
+    avgdl = float(np.mean(dl_all))  # :190
+    hi = HostIndex(indptr=m.indptr, indices=m.indices, data=m.data, doc_lengths=doc_lengths, idf=idf[:V] if V else idf[:0],
+                   avgdl=avgdl, vocabulary=vocabulary, doc_ids=doc_ids)
+    return hi, a, n_total, dl_all
+
+
 class ShardedSearcher:
     """search = local search on this rank's shard -> ONE all-gather of the packed per-shard top-k -> exact merge.
 
@@ -111,24 +180,27 @@ class ShardedSearcher:
         return cls(index.search_device, pack_results, merge_topk_packed_device, group,
                    local_search_packed=index.search_packed_device, merge_packed_out=merge_topk_packed_out_device)
 
-    def search(self, q_ptr, q_term, q_weight, k: int, chunks: int = 0, q_ptr_host=None):
+    def search(self, q_ptr, q_term, q_weight, k: int, chunks: int = 0, q_ptr_host=None, after=None):
         """One batch.  Optionally (chunks > 1) the batch is cut into sub-batches: the all-gather + merge of
         sub-batch i runs on a second HIP stream while sub-batch i+1 is scored (default off: one exchange per batch).  q_ptr_host: the
         same q_ptr on the host (NumPy / CPU tensor), to cut sub-batches without a device-to-host sync."""
         import torch
         import torch.distributed as dist
         exchange = (dist.is_initialized() and dist.get_world_size(self.group) > 1) or getattr(self, "force_exchange", False)
+        kw = {} if after is None else {"after": after}  # srx_search_after: the bound is a GLOBAL (doc, score) row, the same on every shard
         if not exchange:
-            return self.local_search(q_ptr, q_term, q_weight, k)
+            return self.local_search(q_ptr, q_term, q_weight, k, **kw)
+        if after is not None:
+            chunks = 1  # deep pages: plain path
         world = dist.get_world_size(self.group)
         nq = q_ptr.shape[0] - 1
         on_gpu = q_ptr.is_cuda
         if chunks <= 0:
             chunks = 1  # measured on one GPU: cutting the batch costs more (under-filled launches) than it can hide
         if (chunks == 1 or not on_gpu) and self.local_search_packed is not None and self.merge_packed_out is not None:
-            return self._search_packed(q_ptr, q_term, q_weight, k, world)
+            return self._search_packed(q_ptr, q_term, q_weight, k, world, **kw)
         if chunks == 1 or not on_gpu:
-            doc, score, count = self.local_search(q_ptr, q_term, q_weight, k)
+            doc, score, count = self.local_search(q_ptr, q_term, q_weight, k, **kw)
             return self._exchange(doc, score, count, k, world, slot=0)
         # sub-batch boundaries (queries are rows of a CSR: slice q_ptr, rebase, slice terms/weights)
         dev = q_ptr.device
@@ -158,7 +230,7 @@ class ShardedSearcher:
                 t.record_stream(main)
         return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
 
-    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int):
+    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int, after=None):
         """The exchange of :meth:`_exchange` on packed rows end to end: the local search writes packed rows straight
         into the send buffer, the merge reads the received rows in place and writes packed rows, and the results are
         views of the gathered buffer (doc = rows[:, :k], score = rows[:, k:2k] as f32, count = rows[:, 2k]).
@@ -209,7 +281,7 @@ class ShardedSearcher:
                                          torch.empty((world, nq, row), dtype=torch.int32, device=dev))
             mine, recv = bufs
             send = mine
-            self.local_search_packed(q_ptr, q_term, q_weight, k, mine)
+            self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
         else:
             blk = (nq + world - 1) // world
             key = ("pa2a", world, nq, k, dev, slot)
@@ -219,7 +291,7 @@ class ShardedSearcher:
                                          torch.empty((world, blk, row), dtype=torch.int32, device=dev))   # the lists of my query block
             send, recv = bufs
             mine = send[:nq]
-            self.local_search_packed(q_ptr, q_term, q_weight, k, mine)
+            self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
         if not overlap:
             out = exchange(mine, send, recv)
         else:

@@ -456,11 +456,13 @@ class DeviceIndex:
     def workspace_bytes(self, nq: int, k: int) -> int:
         return _capi.check(_capi.lib().srx_search_workspace_bytes(self._h, nq, k), "srx_search_workspace_bytes")
 
-    def search_device(self, q_ptr, q_term, q_weight, k: int, out=None):
+    def search_device(self, q_ptr, q_term, q_weight, k: int, out=None, after=None):
         """Batched search on device tensors (q_ptr i32[nq+1], q_term i32, q_weight f32).
         Returns (doc i32[nq,k], score f32[nq,k], count i32[nq]) device tensors; asynchronous on the current stream.
         Precondition (NOT checked here, the tensors never leave the device): q_ptr starts at 0 and is non-decreasing,
-        0 <= q_term < vocab, no term twice inside a query -- ``validate_queries`` / ``search`` check host batches."""
+        0 <= q_term < vocab, no term twice inside a query -- ``validate_queries`` / ``search`` check host batches.
+        ``after`` = (doc i32[nq] GLOBAL ids, score f32[nq]) device tensors: ``srx_search_after`` -- only docs ranked
+        strictly after that row in (score desc, doc asc) order (the next page of a ranking deeper than max_k)."""
         torch = _torch()
         nq = q_ptr.numel() - 1
         if not (1 <= k <= _capi.limits()["max_k"]):
@@ -473,12 +475,19 @@ class DeviceIndex:
             need = self.workspace_bytes(nq, k)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
-            rc = _capi.lib().srx_search(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out[0]), _ptr(out[1]),
-                                        _ptr(out[2]), _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+            if after is None:
+                rc = _capi.lib().srx_search(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out[0]), _ptr(out[1]),
+                                            _ptr(out[2]), _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+            else:
+                a_doc, a_score = after
+                assert a_doc.dtype == torch.int32 and a_score.dtype == torch.float32 and a_doc.numel() == nq == a_score.numel()
+                rc = _capi.lib().srx_search_after(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, a_doc.data_ptr(),
+                                                  a_score.data_ptr(), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(self._ws),
+                                                  self._ws.numel(), _stream_ptr(torch, self.device))
             _capi.check(rc, "srx_search")
         return out
 
-    def search_packed_device(self, q_ptr, q_term, q_weight, k: int, out=None, stream=None, workspace=None):
+    def search_packed_device(self, q_ptr, q_term, q_weight, k: int, out=None, stream=None, workspace=None, after=None):
         """``srx_search_packed``: the same search, each query's result written as one row
         [k doc ids][k score bit patterns][count] of ``out`` (i32[nq, 2k+1], contiguous) -- the exchange format of the
         sharded search, so no packing kernel runs.  Returns ``out``.  ``stream`` (a torch stream, default: the current
@@ -498,8 +507,14 @@ class DeviceIndex:
                     self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
                 workspace = self._ws
             sp = stream.cuda_stream if stream is not None else _stream_ptr(torch, self.device)
-            rc = _capi.lib().srx_search_packed(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out),
-                                               _ptr(workspace), workspace.numel(), sp)
+            if after is None:
+                rc = _capi.lib().srx_search_packed(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, _ptr(out),
+                                                   _ptr(workspace), workspace.numel(), sp)
+            else:
+                a_doc, a_score = after
+                assert a_doc.dtype == torch.int32 and a_score.dtype == torch.float32 and a_doc.numel() == nq == a_score.numel()
+                rc = _capi.lib().srx_search_after_packed(self._h, _ptr(q_ptr), _ptr(q_term), _ptr(q_weight), nq, k, a_doc.data_ptr(),
+                                                         a_score.data_ptr(), _ptr(out), _ptr(workspace), workspace.numel(), sp)
             _capi.check(rc, "srx_search_packed")
         return out
 
@@ -508,17 +523,20 @@ class DeviceIndex:
 
     def search(self, q_ptr: np.ndarray, q_term: np.ndarray, q_weight: np.ndarray, k: int):
         """Host arrays in, host arrays out (doc, score, count).  The batch is validated first (``validate_queries``);
-        ``search_device`` trusts its device tensors."""
+        ``search_device`` trusts its device tensors.  Any k >= 1: a ranking deeper than the engine's list capacity
+        (``max_k`` = 1024) is paged with ``srx_search_after`` (:func:`deep_search`)."""
         torch = _torch()
         nq = len(q_ptr) - 1
         self.validate_queries(q_ptr, q_term, q_weight)
+        if k < 1:
+            raise ValueError(f"top_k must be >= 1, got {k}")
         if nq == 0:
             return (np.zeros((0, k), np.int32), np.zeros((0, k), np.float32), np.zeros(0, np.int32))
         dev = self.device
         qp = torch.as_tensor(np.ascontiguousarray(q_ptr, dtype=np.int32), device=dev)
         qt = torch.as_tensor(np.ascontiguousarray(q_term, dtype=np.int32), device=dev)
         qw = torch.as_tensor(np.ascontiguousarray(q_weight, dtype=np.float32), device=dev)
-        d, s, c = self.search_device(qp, qt, qw, k)
+        d, s, c = deep_search(self.search_device, qp, qt, qw, k, _capi.limits()["max_k"])
         torch.cuda.synchronize(dev)
         return d.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
 
@@ -656,6 +674,40 @@ class HostBatchPipeline:
     def close(self) -> None:
         _torch().cuda.synchronize(self.index.device)
         self.slots = []
+
+
+def deep_search(search_fn, q_ptr, q_term, q_weight, k: int, page: int):
+    """Top-k for ANY k on top of a search limited to ``page`` rows per call: ``search_fn(q_ptr, q_term, q_weight, kk,
+    after=None | (doc i32[nq], score f32[nq])) -> (doc [nq, kk], score [nq, kk], count [nq])`` torch tensors.  Page p + 1
+    asks for the rows ranked strictly after page p's last row (``srx_search_after``); a query whose page came back short
+    is exhausted (its bound becomes score 0: nothing ranks after it).  This is the reference's unbounded ``top_k`` --
+    ``argpartition`` for any k, the full ``argsort`` when k >= n_docs (retrieval.py:272-284) -- without a list of that
+    size inside the kernels.  Works unchanged on a sharded search (the bound is a GLOBAL (score, doc) row)."""
+    torch = _torch()
+    if k <= page:
+        return search_fn(q_ptr, q_term, q_weight, k)
+    nq = q_ptr.numel() - 1
+    dev = q_ptr.device
+    out_d = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+    out_s = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    out_c = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    after = None
+    got = 0
+    while got < k:
+        kk = min(page, k - got)
+        d, s, c = search_fn(q_ptr, q_term, q_weight, kk) if after is None else search_fn(q_ptr, q_term, q_weight, kk, after=after)
+        out_d[:, got: got + kk] = d
+        out_s[:, got: got + kk] = s
+        out_c += c.to(torch.int32)
+        got += kk
+        if got >= k or int((c == kk).sum().item()) == 0:  # every query exhausted: one sync per page, pages are rare
+            break
+        last = (c.long() - 1).clamp(min=0).unsqueeze(1)
+        full = c == kk
+        a_doc = torch.where(full, d.gather(1, last).squeeze(1), torch.zeros_like(c, dtype=torch.int32)).to(torch.int32).contiguous()
+        a_score = torch.where(full, s.gather(1, last).squeeze(1), torch.zeros_like(c, dtype=torch.float32)).contiguous()
+        after = (a_doc, a_score)
+    return out_d, out_s, out_c
 
 
 def merge_topk_device(in_doc, in_score, in_count, k: int, gathered: bool = False):

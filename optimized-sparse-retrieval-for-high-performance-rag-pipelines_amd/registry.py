@@ -8,7 +8,7 @@ Mirrors, on the HIP engine, the two other call sites of the reference's hot path
 so that the YAML experiments and ``benchmark_efficiency`` (objects with ``build_index_from_corpus`` + ``search``) run
 unmodified.  The registry's dense types (dpr / contriever / splade) go to the ``QuantizedEmbeddingRetriever`` mirror.
 
-``top_k`` is limited by the engine to 1 .. 1024 after clamping to the corpus size (``ValueError`` otherwise).
+``top_k``: any value, like the reference (deep rankings are paged with ``srx_search_after``); ``top_k <= 0`` gives ``{}``.
 """
 from __future__ import annotations
 
@@ -20,7 +20,8 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .index import DeviceIndex, HostIndex, build_host_index, encode_queries, tfidf_idf
+from .backend import SparseBackend
+from .index import DeviceIndex, HostIndex, encode_queries
 
 _BM25_TYPES = ("bm25", "bm25_retriever", "bm25_custom")
 
@@ -32,13 +33,22 @@ class _SparseRetrieverBase:
     strip_cache_key = True
     term_order = "term"  # accumulation order of a doc's contributions (index.encode_queries)
 
-    def __init__(self, k1: float, b: float, device: str, tile_log2: int, use_cache: bool = True):
+    def __init__(self, k1: float, b: float, device: Optional[str], tile_log2: int, use_cache: bool = True, group=None,
+                 shard_searcher_factory=None, sharded: Optional[bool] = None):
         self.k1, self.b = k1, b
-        self.device, self.tile_log2 = device, tile_log2
-        self.host: Optional[HostIndex] = None
-        self.dev: Optional[DeviceIndex] = None
+        # one GPU, or -- inside an initialised torch.distributed group -- doc-range shards (backend.SparseBackend)
+        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded)
+        self.device, self.tile_log2 = self._be.device, tile_log2
         self.query_cache: Optional[Dict[str, Tuple[np.ndarray, np.ndarray]]] = {} if use_cache else None
         self.cache_lock = threading.RLock()
+
+    @property
+    def host(self) -> Optional[HostIndex]:
+        return self._be.host
+
+    @property
+    def dev(self) -> Optional[DeviceIndex]:
+        return self._be.dev
 
     # reference attribute names
     @property
@@ -58,14 +68,7 @@ class _SparseRetrieverBase:
         return csr_matrix((h.data, h.indices, h.indptr), shape=(h.n_docs, h.vocab_size))
 
     def _upload(self):
-        if self.dev is not None:
-            self.dev.close()
-        h = self.host
-        if self.mode == "bm25":
-            self.dev = DeviceIndex.from_host_index(h, k1=self.k1, b=self.b, device=self.device, tile_log2=self.tile_log2)
-        else:
-            self.dev = DeviceIndex.from_csr(h.indptr, h.indices, h.data, h.idf, mode="dot", device=self.device,
-                                            tile_log2=self.tile_log2)
+        self._be.upload(self.mode, self.k1, self.b)
 
     def search(self, queries: Dict[str, str], top_k: int = 10) -> Dict[str, Dict[str, float]]:
         if self.host is None:
@@ -93,12 +96,10 @@ class _SparseRetrieverBase:
             pending[key].append(qid)
         if texts:
             q_ptr, q_term, q_w = encode_queries(texts, self.host.vocabulary, order=self.term_order)
-            k_eff = min(int(top_k), self.host.n_docs)
-            from . import _capi
-            if not (1 <= k_eff <= _capi.limits()["max_k"]):
-                raise ValueError(f"top_k = {top_k} on a corpus of {self.host.n_docs} docs: the HIP engine ranks between 1 and "
-                                 f"{_capi.limits()['max_k']} results per query")
-            docs, scores, counts = self.dev.search(q_ptr, q_term, q_w, k_eff)
+            k_eff = min(int(top_k), self._be.n_docs_total)  # any depth: DeviceIndex.search pages past the engine's 1024-row lists
+            if k_eff <= 0:  # argpartition(...)[:0] keeps nothing (retriever_registry.py:304-312): {} per query, like the reference
+                return results
+            docs, scores, counts = self._be.search_arrays(q_ptr, q_term, q_w, k_eff)
             for i, key in enumerate(keys):
                 if q_ptr[i + 1] == q_ptr[i]:
                     continue
@@ -118,17 +119,16 @@ class _SparseRetrieverBase:
         return {ids[int(i)]: float(s) for i, s in zip(idx, sc) if s > 0}
 
     def close(self):
-        if self.dev is not None:
-            self.dev.close()
-            self.dev = None
+        self._be.close()
 
 
 class OptimizedBM25Retriever(_SparseRetrieverBase):
     """retriever_registry.py:120-356 (``method='tfidf'`` is BM25 with k1=1000, b=0 there, :593-595)."""
 
-    def __init__(self, method: str = "bm25", model: str = None, k1: float = 1.2, b: float = 0.75, device: str = "cuda:0",
+    def __init__(self, method: str = "bm25", model: str = None, k1: float = 1.2, b: float = 0.75, device: Optional[str] = None,
                  tile_log2: int = 14, **kwargs):
-        super().__init__(k1, b, device, tile_log2, use_cache=kwargs.get("cache_queries", True))
+        super().__init__(k1, b, device, tile_log2, use_cache=kwargs.get("cache_queries", True), group=kwargs.get("group"),
+                         shard_searcher_factory=kwargs.get("shard_searcher_factory"), sharded=kwargs.get("sharded"))
         self.method = method.lower()
         self.model_name = model
         self.use_simd = kwargs.get("use_simd", True)  # accepted, meaningless here
@@ -136,7 +136,7 @@ class OptimizedBM25Retriever(_SparseRetrieverBase):
     def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
         if not corpus:
             raise ValueError("Empty corpus provided")  # retriever_registry.py:155-156
-        self.host = build_host_index(corpus, idf_kind="bm25")
+        self._be.build(corpus, idf_kind="bm25")
         self._upload()
 
 
@@ -152,15 +152,17 @@ class OptimizedRetriever(_SparseRetrieverBase):
 
     strip_cache_key = False  # its cache key is f"{query_text}:{top_k}" (:340)
 
-    def __init__(self, config: Dict[str, Any], hardware_info: Optional[Dict[str, Any]] = None, device: str = "cuda:0",
-                 tile_log2: int = 14, cache_dir: str = ".rag_cache", accumulation: str = "token"):
+    def __init__(self, config: Dict[str, Any], hardware_info: Optional[Dict[str, Any]] = None, device: Optional[str] = None,
+                 tile_log2: int = 14, cache_dir: str = ".rag_cache", accumulation: str = "token", group=None,
+                 shard_searcher_factory=None, sharded: Optional[bool] = None):
         if accumulation not in ("token", "term"):
             raise ValueError("accumulation must be 'token' or 'term'")
         self.term_order = accumulation
         params = config.get("params", {}) or {}
         hardware_info = hardware_info or {"memory_gb": 8, "cores": 4}
         super().__init__(params.get("k1", 1.2), params.get("b", 0.75), device, tile_log2,
-                         use_cache=hardware_info.get("memory_gb", 8) > 4)
+                         use_cache=hardware_info.get("memory_gb", 8) > 4, group=group, shard_searcher_factory=shard_searcher_factory,
+                         sharded=sharded)
         self.config, self.hardware = config, hardware_info
         self.method = config.get("type", "bm25").lower()
         self.mode = "bm25" if self.method in ("bm25", "bm25_custom") else "dot"  # :258-261, :378-399
@@ -170,11 +172,12 @@ class OptimizedRetriever(_SparseRetrieverBase):
     def build_index_from_corpus(self, corpus: Dict[str, Dict]) -> None:
         corpus_hash = hashlib.md5(str(sorted(corpus.keys())[:1000]).encode()).hexdigest()[:8]  # :189
         cache_file = self.cache_dir / f"{self.method}_index_{corpus_hash}.npz"
-        if self.use_cache and cache_file.exists():
-            self.host = load_index_npz(cache_file)
+        sharded = self._be.sharded()  # the .npz cache holds a whole-corpus index: shards are always built from the corpus
+        if self.use_cache and cache_file.exists() and not sharded:
+            self._be.set_host(load_index_npz(cache_file))
         else:
-            self.host = build_host_index(corpus, idf_kind="bm25" if self.mode == "bm25" else "tfidf")
-            if self.use_cache:
+            self._be.build(corpus, idf_kind="bm25" if self.mode == "bm25" else "tfidf")
+            if self.use_cache and not sharded:
                 self.cache_dir.mkdir(exist_ok=True)
                 save_index_npz(cache_file, self.host)
         self._upload()

@@ -6,12 +6,20 @@ Same names, argument meaning, result shape and error behaviour for the hot path:
 ``clear_cache()`` (:464), ``close()`` / context manager (:495-506), and the dense ``search_by_vector`` (:402-436).  The
 document store (MemoryIndex) is outside this build's scope.
 
-``top_k``: after clamping to the corpus size it must be <= 1024 (the engine's list capacity; ``ValueError`` otherwise --
-the reference accepts any value); ``top_k <= 0`` returns ``{}`` for every query like the reference's ``argpartition``.
+``top_k``: any value, like the reference (``k >= n_docs`` ranks the whole corpus, :281-284): rankings deeper than the
+engine's 1024-row lists are paged with ``srx_search_after``; ``top_k <= 0`` returns ``{}`` for every query like the
+reference's ``argpartition``.
 
 What changes underneath: ``search_bm25`` scores the WHOLE query dict as one batch through
 ``srx_search`` (libsparse_rx.so) instead of looping ``simd_bm25_score`` + ``fast_topk_selection`` per query
 (:210-229, :256-284).  There is no CPU fallback: without the HIP library / a GPU the calls raise.
+
+Multi-GPU: when the process is a rank of an initialised ``torch.distributed`` group of more than one rank (one process
+per GPU, backend "nccl" = RCCL), the SAME two calls shard the index by doc-id range: every rank passes the same corpus /
+query dicts, ``build_bm25_index`` builds the rank's doc range with corpus-wide vocabulary, idf and avgdl
+(distributed.build_sharded_host_index), ``search_bm25`` scores the batch on every shard, exchanges the per-shard top-k
+over RCCL and merges (distributed.ShardedSearcher); every rank returns the dicts the single-GPU service returns
+(backend.SparseBackend holds that wiring for this class and the registry mirrors).
 """
 from __future__ import annotations
 
@@ -23,8 +31,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import _capi
-from .index import DeviceIndex, HostIndex, build_host_index, encode_queries
+from .backend import SparseBackend
+from .index import DeviceIndex, HostIndex, encode_queries
 
 logger = logging.getLogger(__name__)
 
@@ -35,7 +43,8 @@ class RetrievalService:
     """BM25 retrieval with the reference's API; scoring + top-k run on the GPU."""
 
     def __init__(self, index_path=None, embedding_path=None, num_workers: int = 4, cache_size: int = 1000, *,
-                 device: str = "cuda:0", tile_log2: int = 14, **compat_kwargs):
+                 device: Optional[str] = None, tile_log2: int = 14, group=None, sharded: Optional[bool] = None,
+                 shard_searcher_factory=None, **compat_kwargs):
         # index_path / embedding_path / num_workers are accepted for signature compatibility (retrieval.py:98-102);
         # README-only kwargs (use_simd, batch_size, monitor, ...) are swallowed.
         self.index_path = index_path
@@ -43,10 +52,12 @@ class RetrievalService:
         self.num_workers = num_workers
         self.cache_size = cache_size
         self.logger = logger
-        self.device = device
+        # group: the torch.distributed group to shard over (None = the default group, when one is initialised);
+        # shard_searcher_factory: test hook of backend.SparseBackend (the product never sets it)
+        # sharded: None = automatic (a group of more than one rank), True = the sharded path even in a group of one rank
+        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded)
+        self.device = self._be.device
         self.tile_log2 = tile_log2
-        self.host: Optional[HostIndex] = None
-        self.dev: Optional[DeviceIndex] = None
         self.k1: float = 1.2   # retrieval.py:116
         self.b: float = 0.75   # retrieval.py:117
         self._built_k1b: Optional[Tuple[float, float]] = None
@@ -55,6 +66,14 @@ class RetrievalService:
         self.build_time = 0.0
 
     # -- reference attribute names (read-only views) -----------------------------------------------------
+    @property
+    def host(self) -> Optional[HostIndex]:
+        return self._be.host  # sharded: this rank's rows, corpus-wide vocabulary / idf / avgdl / doc ids
+
+    @property
+    def dev(self) -> Optional[DeviceIndex]:
+        return self._be.dev
+
     @property
     def vocabulary(self) -> Dict[str, int]:
         return self.host.vocabulary if self.host else {}
@@ -69,7 +88,7 @@ class RetrievalService:
 
     @property
     def doc_lengths(self):
-        return self.host.doc_lengths if self.host else None
+        return self._be.doc_lengths  # the whole corpus' lengths (sharded: all-gathered at build)
 
     @property
     def avgdl(self) -> float:
@@ -87,17 +106,14 @@ class RetrievalService:
     def build_bm25_index(self, corpus: Dict[str, Dict]) -> None:
         """retrieval.py:129-201 on the host (bit-equal arrays), then the device inverted index."""
         t0 = time.perf_counter()
-        self.host = build_host_index(corpus, idf_kind="bm25")
+        self._be.build(corpus, idf_kind="bm25")
         self._upload()
         self.build_time = time.perf_counter() - t0
         self.logger.info("BM25 index built in %.2fs (%d docs, %d terms, %d postings)", self.build_time,
                          self.host.n_docs, self.host.vocab_size, self.host.nnz)
 
     def _upload(self) -> None:
-        if self.dev is not None:
-            self.dev.close()
-        self.dev = DeviceIndex.from_host_index(self.host, k1=self.k1, b=self.b, device=self.device,
-                                               tile_log2=self.tile_log2)
+        self._be.upload("bm25", self.k1, self.b)
         self._built_k1b = (self.k1, self.b)
         with self.cache_lock:
             self.query_cache.clear()
@@ -107,10 +123,9 @@ class RetrievalService:
         """retrieval.py:203-231 semantics; one batched GPU call for all uncached queries."""
         if self.host is None:
             raise ValueError("BM25 index not built. Call build_bm25_index() first.")  # :205-206
-        k_eff = min(int(top_k), self.host.n_docs)  # k >= n_docs -> everything, ranked (:281-284)
-        if k_eff > _capi.limits()["max_k"]:
-            raise ValueError(f"top_k = {top_k} on a corpus of {self.host.n_docs} docs: the HIP engine ranks at most "
-                             f"{_capi.limits()['max_k']} results per query (the reference accepts any top_k)")
+        # k >= n_docs -> everything, ranked (:281-284); any depth: past its 1024-row lists the engine pages with
+        # srx_search_after (index.deep_search)
+        k_eff = min(int(top_k), self._be.n_docs_total)
         if k_eff <= 0:  # the reference's argpartition(-scores, 0)[:0] keeps nothing (:276-279)
             return {qid: {} for qid in queries}
         if (self.k1, self.b) != self._built_k1b:
@@ -137,7 +152,7 @@ class RetrievalService:
             pending[key].append(qid)
         if texts:
             q_ptr, q_term, q_weight = encode_queries(texts, self.host.vocabulary)
-            docs, scores, counts = self.dev.search(q_ptr, q_term, q_weight, k_eff)
+            docs, scores, counts = self._be.search_arrays(q_ptr, q_term, q_weight, k_eff)
             for i, key in enumerate(keys):
                 if q_ptr[i + 1] == q_ptr[i]:  # no token / no in-vocabulary term -> {} and nothing cached (:237-238, :251-252)
                     continue
@@ -218,12 +233,15 @@ class RetrievalService:
         """Same keys as retrieval.py:471-493, plus backend facts."""
         stats: Dict[str, object] = {"cache_size": 0, "query_cache_size": len(self.query_cache),
                                     "numba_available": NUMBA_AVAILABLE, "backend": "hip-gfx950"}
+        stats["n_gpus"] = self._be.world()  # doc-range shards (one process per GPU); 1 = the whole index on one card
         if self.host is not None:
-            h = self.host
-            density = h.nnz / (h.n_docs * h.vocab_size)
+            h = self.host  # sharded: this rank's rows -- density and memory are the shard's, num_docs the corpus'
+            density = h.nnz / max(1, h.n_docs * h.vocab_size)
             memory_mb = (h.data.nbytes + h.indices.nbytes + h.indptr.nbytes) / (1024 * 1024)
-            stats.update({"num_docs": h.n_docs, "vocab_size": h.vocab_size, "matrix_density": density,
+            stats.update({"num_docs": self._be.n_docs_total, "vocab_size": h.vocab_size, "matrix_density": density,
                           "bm25_memory_mb": memory_mb, "avgdl": h.avgdl})
+            if self._be.sharded():
+                stats["shard_docs"], stats["shard_doc_base"] = h.n_docs, self._be.doc_base
         if self.dev is not None:
             stats["device_index_mb"] = self.dev.device_bytes() / (1024 * 1024)
         return stats
@@ -235,7 +253,5 @@ class RetrievalService:
         self.close()
 
     def close(self) -> None:
-        if self.dev is not None:
-            self.dev.close()
-            self.dev = None
+        self._be.close()
         self.clear_cache()

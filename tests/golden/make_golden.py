@@ -24,6 +24,8 @@ reference produced for them:
   ref_cache/*.npz      the ``.rag_cache/{method}_index_{hash}.npz`` files the reference itself wrote
                        (``_save_cached_index``, :280-296) for the bm25 and splade types -- data files, read with
                        ``allow_pickle=False``
+  text_deep.npz        2600 docs through ``search_bm25`` at top_k = 1500 and 5000 (>= n_docs): rankings deeper than the
+                       engine's 1024-row lists (run with the argument ``deep`` to refresh only this one)
   dense_uint8_asym.npz/.json  the same retriever with quantization_method="asymmetric" (uint8 + scale / min table)
   dense_int8.npz/.json ``QuantizedEmbeddingRetriever`` (symmetric INT8): quantized corpus, per-query similarity rows
                        and ``search`` results for recorded embeddings (run with the argument ``dense`` to refresh
@@ -378,7 +380,36 @@ def make_dense_fixture():
         json.dump({"doc_ids": r.doc_ids, "qids": list(qtexts), "results": results}, f, indent=0)
 
 
+def make_deep_fixture(tmp):
+    """text_deep.npz: a corpus of MORE than 1024 docs through the reference's ``search_bm25`` at top_k beyond 1024 --
+    k = 1500 (argpartition + argsort, retrieval.py:276-279) and k = 5000 >= n_docs (the full argsort branch, :281-284).
+    Arrays only: the doc texts (newline-joined, utf-8 bytes), the queries, and per (k, query) the returned rows
+    (doc row ids in rank order, fp32 scores)."""
+    rng = np.random.default_rng(20257)
+    vocab_words = [f"w{i}" for i in range(400)]
+    corpus = zipf_text_corpus(rng, 2600, vocab_words)
+    svc = new_service(tmp)
+    svc.build_bm25_index(corpus)
+    queries = {"d0": "w8 w9 w10 w11 w12", "d1": "w6 w20 w33 w47", "d2": "w250 w399 w120 w77 w5", "d3": "w0",
+               "d4": "w9 w9 w300 w14 w15 w16", "d5": "w7 w13 w21 w34 w55 w89 w144 w233 w377"}
+    row = {d: i for i, d in enumerate(svc.doc_ids)}
+    out = {"texts": np.frombuffer("\n".join(corpus[d]["text"] for d in svc.doc_ids).encode("utf-8"), dtype=np.uint8),
+           "qids": np.array(list(queries)), "qtexts": np.array(list(queries.values()))}
+    for k in (1500, 5000):
+        svc.clear_cache()
+        res = svc.search_bm25(queries, top_k=k)
+        for qid in queries:
+            out[f"k{k}_{qid}_doc"] = np.array([row[d] for d in res[qid]], dtype=np.int32)
+            out[f"k{k}_{qid}_score"] = np.array(list(res[qid].values()), dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "text_deep.npz"), **out)
+    svc.close()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "deep":  # only the deep-ranking fixture
+        with tempfile.TemporaryDirectory() as tmp:
+            make_deep_fixture(tmp)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dense":  # only the dense fixture (the others stay as committed)
         make_dense_fixture()
         sys.exit(0)
@@ -393,6 +424,7 @@ if __name__ == "__main__":
         make_csr_fixture(tmp)
         make_registry_fixture(tmp, corpus, queries)
         make_pipeline_fixture(tmp, corpus, queries)
+        make_deep_fixture(tmp)
     make_dense_fixture()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

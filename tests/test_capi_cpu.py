@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libsparse_rx.so does not export {name}"
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
-    assert L.srx_version() == 210
+    assert L.srx_version() == 300
 
 
 def test_limits_and_error_strings():

@@ -195,3 +195,104 @@ def test_global_term_bounds_collective(no_table_rank):
             p.join(timeout=120)
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         assert dict(ret) == {r: True for r in range(world)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the drop-in API under torch.distributed: RetrievalService / OptimizedBM25Retriever shard by doc range
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_searcher_factory(host, doc_base, mode, k1, b, group):
+    """TEST backend behind the sharding protocol: the CPU oracle scores this rank's rows (the product wiring puts the HIP
+    engine here: backend.SparseBackend.upload)."""
+    import sparse_rx
+    omode = oracle.MODE_BM25_F32 if mode == "bm25" else oracle.MODE_TFIDF_F32
+
+    def local_search(q_ptr, q_term, q_w, kk, after=None):
+        K = kk if after is None else host.n_docs  # a page: rank the shard, keep the rows after the bound
+        d, s, n = oracle.search_batch(host.indptr, host.indices, host.data, host.doc_lengths, host.idf, q_ptr.numpy(), q_term.numpy(),
+                                      q_w.numpy(), min(K, host.n_docs), k1, b, host.avgdl, mode=omode)
+        d = np.where(d >= 0, d + doc_base, -1).astype(np.int32)
+        od = np.full((len(n), kk), -1, np.int32)
+        os_ = np.zeros((len(n), kk), np.float32)
+        on = np.zeros(len(n), np.int32)
+        for q in range(len(n)):
+            dd, ss = d[q, : n[q]], s[q, : n[q]]
+            if after is not None:
+                ad, as_ = int(after[0][q]), float(after[1][q])
+                keep = (ss < as_) | ((ss == as_) & (dd > ad))
+                dd, ss = dd[keep], ss[keep]
+            m = min(kk, len(dd))
+            od[q, :m], os_[q, :m], on[q] = dd[:m], ss[:m], m
+        return torch.from_numpy(od), torch.from_numpy(os_), torch.from_numpy(on)
+
+    return sparse_rx.ShardedSearcher(local_search, _pack, _merge_packed, group)
+
+
+def _service_worker(rank, world, port, golden_dir, ret):
+    import json
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sparse_rx
+    from parity import assert_ranked_equal
+    from test_oracle_golden import _deep_fixture
+    z = np.load(os.path.join(golden_dir, "text_small.npz"))
+    with open(os.path.join(golden_dir, "text_small.json"), encoding="utf-8") as f:
+        j = json.load(f)
+    svc = sparse_rx.RetrievalService(shard_searcher_factory=_oracle_searcher_factory)
+    svc.build_bm25_index(j["corpus"])
+    # corpus-wide state equals the reference's single-process state; the rows are this rank's slice of it
+    a, b = sparse_rx.shard_range(len(j["corpus"]), world, rank)
+    assert svc.doc_ids == list(z["doc_ids"]) and svc.avgdl == float(z["avgdl"])
+    assert [t for t, _ in sorted(svc.vocabulary.items(), key=lambda kv: kv[1])] == list(z["vocabulary"])
+    assert np.array_equal(svc.idf_weights.view(np.uint32), z["idf"].view(np.uint32))
+    assert np.array_equal(svc.doc_lengths, z["doc_lengths"]) and np.array_equal(svc.host.doc_lengths, z["doc_lengths"][a:b])
+    lo, hi = z["tf_indptr"][a], z["tf_indptr"][b]
+    assert np.array_equal(svc.host.indptr, z["tf_indptr"][a: b + 1] - lo)
+    assert np.array_equal(svc.host.indices, z["tf_indices"][lo:hi]) and np.array_equal(svc.host.data, z["tf_data"][lo:hi])
+    st = svc.get_stats()
+    assert st["n_gpus"] == world and st["num_docs"] == len(j["corpus"]) and st["shard_docs"] == b - a
+    row = {d: i for i, d in enumerate(svc.doc_ids)}
+    qids = list(z["score_qids"])
+    for k in ("3", "10", "1000"):
+        got = svc.search_bm25(j["queries"], top_k=int(k))
+        exp = j["results"][k]
+        assert list(got.keys()) == list(exp.keys())
+        for qid in exp:
+            g, e = got[qid], exp[qid]
+            full = z["full_scores"][qids.index(qid)] if qid in qids else None
+            assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                                np.array(list(e.values()), np.float32), k=min(int(k), len(row)), full_scores=full, label=f"sharded k={k} {qid}")
+        assert svc.search_bm25(j["queries"], top_k=int(k)) == got  # cache hits
+    svc.close()
+    # the registry twin, and a ranking deeper than one page (2600 docs, k = 1500 / 5000 -> srx_search_after pages)
+    corpus, queries, exp = _deep_fixture(golden_dir)
+    reg = sparse_rx.OptimizedBM25Retriever(shard_searcher_factory=_oracle_searcher_factory)
+    reg.build_index_from_corpus(corpus)
+    row = {d: i for i, d in enumerate(reg.doc_ids)}
+    for k in (1500, 5000):
+        got = reg.search(queries, top_k=k)
+        for qid in queries:
+            ed, es = exp[k][qid]
+            g = got[qid]
+            assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), ed, es, k=min(k, len(row)), label=f"sharded deep k={k} {qid}")
+    reg.close()
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_retrieval_service_shards_under_torch_distributed(world, golden_dir):
+    """RetrievalService.build_bm25_index / search_bm25 (retrieval.py:129-231) called by every rank of a gloo group: the
+    corpus-wide vocabulary / idf / avgdl equal the reference's, the rank holds its doc range only, and the dicts every
+    rank returns equal the reference's single-process results (tests/golden/text_small.json, text_deep.npz)."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_service_worker, args=(r, world, port, golden_dir, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert dict(ret) == {r: True for r in range(world)}

@@ -87,6 +87,67 @@ def test_text_golden_end_to_end(rx, golden_dir):
     svc.close()
 
 
+def test_deep_ranking_golden_and_search_after(rx, golden_dir):
+    """top_k > 1024 (the engine's list capacity) and top_k >= n_docs (retrieval.py:272-284): served in pages by
+    srx_search_after.  (1) against rows the REFERENCE returned at top_k = 1500 / 5000 on a 2600-doc corpus
+    (tests/golden/text_deep.npz); (2) against the oracle at k = 5000 / 2048 / 1025 on corpora that take the tier-2
+    kernel's hash, flat, wave-dense and block-dense paths; (3) a search-after page equals the matching slice of one deeper
+    search, also for k <= 112 (where tier 1 would otherwise serve)."""
+    import torch
+    from test_oracle_golden import _deep_fixture
+    from sparse_rx import synth
+    corpus, queries, exp = _deep_fixture(golden_dir)
+    for tl in (6, 10):
+        svc = rx.RetrievalService(device="cuda:0", tile_log2=tl)
+        svc.build_bm25_index(corpus)
+        row = {d: i for i, d in enumerate(svc.doc_ids)}
+        for k in (1500, 5000):
+            svc.clear_cache()
+            got = svc.search_bm25(queries, top_k=k)
+            for qid in queries:
+                ed, es = exp[k][qid]
+                g = got[qid]
+                assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), ed, es, k=min(k, len(row)),
+                                    label=f"deep golden tile={tl} k={k} {qid}")
+        svc.close()
+    reg = rx.OptimizedBM25Retriever(device="cuda:0", tile_log2=8)  # the registry twin accepts any top_k too; <= 0 gives {}
+    reg.build_index_from_corpus(corpus)
+    assert reg.search(queries, top_k=0) == {q: {} for q in queries} and reg.search(queries, top_k=-3) == {q: {} for q in queries}
+    g = reg.search(queries, top_k=5000)
+    assert [len(g[q]) for q in queries] == [len(exp[5000][q][0]) for q in queries]
+    reg.close()
+    # (2) oracle, several layouts
+    c = synth.zipf_corpus_np(60_000, 3_000, 40, seed=77)
+    _, idf, avgdl = synth.corpus_stats(c)
+    q = synth.queries_np(24, c.vocab, 6, seed=78, dist="zipf")
+    for kw in (dict(tile_log2=14), dict(tile_log2=12, unit_tiles=1), dict(tile_log2=9), dict(tile_log2=12, unit_tiles=2)):
+        ix = _dev_index(rx, c, idf, avgdl, **kw)
+        for k in (5000, 2048, 1025):
+            _assert_exact(ix.search(*q, k), _oracle_batch(c, idf, avgdl, q, k), f"deep zipf {kw} k={k}")
+        ix.close()
+    cs = synth.splade_corpus_np(30_000, 2_000, 80, seed=79)
+    ones = np.ones(cs.vocab, dtype=np.float32)
+    qs = synth.queries_np(12, cs.vocab, 40, seed=80, dist="zipf", s=0.7, weights="learned")
+    for vd, tl, ut in (("f16", 12, 1), ("f32", 13, 0)):
+        ix = rx.DeviceIndex.from_csr(cs.indptr, cs.indices, cs.data, ones, mode="dot", val_dtype=vd, tile_log2=tl, unit_tiles=ut)
+        _assert_exact(ix.search(*qs, 3000), _oracle_batch(cs, ones, 1.0, qs, 3000, mode=oracle.MODE_TFIDF_F32), f"deep splade {vd} {tl}")
+        ix.close()
+    # (3) pages by hand on device tensors, small k
+    ix = _dev_index(rx, c, idf, avgdl, tile_log2=12)
+    dq = tuple(torch.as_tensor(x, device="cuda:0") for x in q)
+    d_all, s_all, c_all = (t.cpu().numpy() for t in ix.search_device(*dq, 300))
+    for k_page in (100, 64):
+        after, got = None, 0
+        while got + k_page <= 300:
+            d, s, n = ix.search_device(*dq, k_page, after=after)
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy(), d_all[:, got: got + k_page]) and np.array_equal(s.cpu().numpy().view(np.uint32), s_all[:, got: got + k_page].view(np.uint32))
+            full = n == k_page
+            after = (torch.where(full, d[:, -1], torch.zeros_like(d[:, -1])).contiguous(), torch.where(full, s[:, -1], torch.zeros_like(s[:, -1])).contiguous())
+            got += k_page
+    ix.close()
+
+
 @pytest.mark.parametrize("tile_log2,super_log2,target_blocks", [(6, 0, 0), (8, 8, 4096), (7, 11, 1), (14, 0, 0)])
 def test_csr_zipf_golden(rx, golden_dir, tile_log2, super_log2, target_blocks):
     z = np.load(os.path.join(golden_dir, "csr_zipf.npz"))
@@ -222,8 +283,9 @@ def test_edge_cases(rx):
         assert got[2][0] == 0 and got[2][4] == 0
     with pytest.raises(ValueError):
         ix.search(*q, 0)
-    with pytest.raises(ValueError):
-        ix.search(*q, 1025)
+    for k in (1025, 2500):  # deeper than the engine's lists: paged with srx_search_after (index.deep_search)
+        got = ix.search(*q, k)
+        _assert_exact(got, _oracle_batch(c, idf, avgdl, q, k), f"edge deep k={k}")
     # host batches are validated before any launch: out-of-range / repeated terms never reach the kernels
     with pytest.raises(ValueError, match="out of range"):
         ix.search(np.array([0, 2], np.int32), np.array([1, 700], np.int32), np.ones(2, np.float32), 10)
@@ -751,6 +813,36 @@ def test_sharded_searcher_overlap_on_one_gpu(rx):
                 for i, (o, e) in enumerate(zip(outs, exps)):
                     _assert_exact(tuple(x.contiguous().cpu().numpy() for x in o), e, f"{mode} overlap={overlap} batch {i}")
         ix.close()
+        # The drop-in API on the same RCCL group: RetrievalService(sharded=True) builds its doc range through the collectives
+        # of distributed.build_sharded_host_index and searches through ShardedSearcher (srx_search_packed -> all-to-all ->
+        # srx_merge_topk_packed_out -> all-gather); the dicts must be the reference's single-process results.
+        golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        with open(os.path.join(golden, "text_small.json"), encoding="utf-8") as f:
+            j = json.load(f)
+        svc = rx.RetrievalService(device="cuda:0", tile_log2=6, sharded=True)
+        svc.build_bm25_index(j["corpus"])
+        assert svc._be.searcher is not None and svc.get_stats()["n_gpus"] == 1
+        row = {d: i for i, d in enumerate(svc.doc_ids)}
+        for kk in ("3", "10", "1000"):
+            got = svc.search_bm25(j["queries"], top_k=int(kk))
+            exp = j["results"][kk]
+            assert list(got.keys()) == list(exp.keys())
+            for qid in exp:
+                g, e = got[qid], exp[qid]
+                assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                                    np.array(list(e.values()), np.float32), k=min(int(kk), len(row)), label=f"sharded service k={kk} {qid}")
+        svc.close()
+        from test_oracle_golden import _deep_fixture
+        corpus, queries, exp = _deep_fixture(golden)  # deeper than one page: srx_search_after_packed through the exchange
+        reg = rx.OptimizedBM25Retriever(device="cuda:0", tile_log2=8, sharded=True)
+        reg.build_index_from_corpus(corpus)
+        row = {d: i for i, d in enumerate(reg.doc_ids)}
+        got = reg.search(queries, top_k=5000)
+        for qid in queries:
+            ed, es = exp[5000][qid]
+            g = got[qid]
+            assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), ed, es, k=len(row), label=f"sharded deep {qid}")
+        reg.close()
     finally:
         dist.destroy_process_group()
 

@@ -220,3 +220,32 @@ def test_c1_fiqa_shaped_plumbing():
         idx, sc = np_oracle.topk_ranked(s, 10)
         keep = sc > 0
         assert np.array_equal(od[q, :oc[q]], idx[keep]) and np.array_equal(osc[q, :oc[q]].view(np.uint32), sc[keep].view(np.uint32))
+
+
+def _deep_fixture(golden_dir):
+    """tests/golden/text_deep.npz (written by the reference's search_bm25 at top_k = 1500 / 5000 on 2600 docs):
+    (corpus dict, queries dict, {k: {qid: (doc rows, scores)}})."""
+    z = np.load(os.path.join(golden_dir, "text_deep.npz"))
+    texts = bytes(z["texts"]).decode("utf-8").split("\n")
+    corpus = {f"doc{i}": {"text": t} for i, t in enumerate(texts)}
+    queries = {str(q): str(t) for q, t in zip(z["qids"], z["qtexts"])}
+    exp = {k: {q: (z[f"k{k}_{q}_doc"], z[f"k{k}_{q}_score"]) for q in queries} for k in (1500, 5000)}
+    return corpus, queries, exp
+
+
+def test_deep_ranking_matches_reference(golden_dir):
+    """top_k beyond 1024 and top_k >= n_docs (retrieval.py:272-284): the oracle's unbounded top-k reproduces the rows the
+    reference returned (modulo its unspecified order inside exact ties)."""
+    import sparse_rx
+    corpus, queries, exp = _deep_fixture(golden_dir)
+    hi = sparse_rx.build_host_index(corpus)
+    q = sparse_rx.encode_queries(list(queries.values()), hi.vocabulary)
+    assert hi.n_docs == 2600
+    for k in (1500, 5000):
+        kk = min(k, hi.n_docs)
+        d, s, c = oracle.search_batch(hi.indptr, hi.indices, hi.data, hi.doc_lengths, hi.idf, q[0], q[1], q[2], kk, 1.2, 0.75, hi.avgdl)
+        for i, qid in enumerate(queries):
+            ed, es = exp[k][qid]
+            assert c[i] == len(ed), (k, qid)
+            assert_ranked_equal(d[i, : c[i]], s[i, : c[i]], ed, es, k=kk, label=f"deep k={k} {qid}")
+    assert max(len(v[0]) for v in exp[5000].values()) > 1024  # the fixture does reach past the engine's list capacity
