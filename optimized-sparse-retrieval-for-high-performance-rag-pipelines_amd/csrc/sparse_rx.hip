@@ -82,6 +82,54 @@ __device__ __forceinline__ bool after_bound(const ScoreShared &S, unsigned b, in
     return b < S.ub_bits || (b == S.ub_bits && doc > S.ub_doc);
 }
 
+// Rank the block's final list (tk.count <= k entries, unordered) by (score desc, doc asc) -- bitonic sort of 64-bit keys
+// score bits : 0x7FFFFFFF - doc in `sortkey` (KMAX words of LDS) -- and write the padded result row.
+__device__ void block_rank_emit(const TopkShared &tk, unsigned long long *sortkey, int k, int64_t doc_base,
+                                int32_t *__restrict__ row_doc, float *__restrict__ row_score, int32_t *__restrict__ row_count) {
+    const int tid = threadIdx.x;
+    const unsigned cnt = tk.count;
+    unsigned n = 1;
+    while (n < cnt) n <<= 1;
+    for (unsigned i = tid; i < n; i += THREADS)
+        sortkey[i] = i < cnt ? (((unsigned long long)tk.bits[i] << 32) | (0x7FFFFFFFu - (unsigned)tk.doc[i])) : 0ull;
+    __syncthreads();
+    for (unsigned size = 2; size <= n; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned i = tid; i < (n >> 1); i += THREADS) {
+                const unsigned pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = sortkey[pos], b = sortkey[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) {
+                    sortkey[pos] = b;
+                    sortkey[pos + stride] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (unsigned i = tid; i < (unsigned)k; i += THREADS) {
+        if (i < cnt) {
+            const unsigned long long x = sortkey[i];
+            row_doc[i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
+            row_score[i] = __uint_as_float((unsigned)(x >> 32));
+        } else {
+            row_doc[i] = -1;
+            row_score[i] = 0.0f;
+        }
+    }
+    if (tid == 0) *row_count = (int)cnt;
+}
+
+// Where the tier-2 kernel writes FINAL rows (queries that are one work item: nothing is left for the merge kernel) and the
+// worklist length it reports back to the host (pinned word, read without synchronisation by the next call: a hint only).
+struct Tier2Final {
+    int32_t *out_doc;
+    float *out_score;
+    int32_t *out_count;
+    int64_t ors, ocs;
+    int *hint;
+};
+
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
 // scores into the running top-k.  nt = terms in this pass.
 template <typename VT>
@@ -881,7 +929,8 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                             int n_splits, int n_whole, int tpu, int n_super, int dbg, const unsigned *__restrict__ ovf,
                             int ovf_words, int lists_per_q, int32_t *__restrict__ cand_doc,
                             float *__restrict__ cand_score, int32_t *__restrict__ cand_count,
-                            const int32_t *__restrict__ after_doc, const float *__restrict__ after_score, int64_t doc_base) {
+                            const int32_t *__restrict__ after_doc, const float *__restrict__ after_score, int64_t doc_base,
+                            const Tier2Final &fin) {
     const int tid = threadIdx.x;
     T2_T0();
     int q, split, nsq;
@@ -1138,6 +1187,30 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     T2(0);
     topk_shrink(k, S.tk, S.tbl);
     T2(5); T2C(12);
+    if (nsq == 1 && fin.out_doc != nullptr) {
+        // An unsplit query is ONE work item: this block holds everything tier 1 did not score.  Fold tier 1's list of the
+        // same query in (it was complete before this kernel started; its docs come from other units), rank, and write the
+        // final row here -- the merge kernel only ever sees split queries.
+        const int64_t l1 = (int64_t)q * lists_per_q;
+        const int c1 = min(max(cand_count[l1], 0), k);
+        const unsigned tau = S.tk.tau;  // k entries >= tau are in the list once a selection has run: nothing below can enter
+        unsigned ub[KPT];
+        int ud[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = tid + j * THREADS;
+            const unsigned b = i < c1 ? __float_as_uint(cand_score[l1 * k + i]) : 0u;
+            ub[j] = (b >= tau && b != 0u) ? b : 0u;
+            ud[j] = i < c1 ? cand_doc[l1 * k + i] : 0;
+        }
+        __syncthreads();
+        topk_fold<KPT, false>(ub, ud, k, S.tk, S.tbl);
+        __syncthreads();
+        block_rank_emit(S.tk, reinterpret_cast<unsigned long long *>(S.tbl), k, doc_base, fin.out_doc + (int64_t)q * fin.ors,
+                        fin.out_score + (int64_t)q * fin.ors, fin.out_count + (int64_t)q * fin.ocs);
+        if (tid == 0) cand_count[l1] = -1;  // final (as when tier 1 finishes a query on its own)
+        return;
+    }
     const unsigned cnt = S.tk.count;
     const int64_t o = list * k;
     for (unsigned i = tid; i < cnt; i += THREADS) {
@@ -1160,13 +1233,15 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
                                                                float *__restrict__ cand_score,
                                                                int32_t *__restrict__ cand_count,
                                                                const int32_t *__restrict__ after_doc,
-                                                               const float *__restrict__ after_score, int64_t doc_base) {
+                                                               const float *__restrict__ after_score, int64_t doc_base,
+                                                               const Tier2Final fin) {
     __shared__ ScoreShared S;
     const int n_work = work[0];
+    if (fin.hint != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fin.hint = n_work;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // the previous block's LDS state is dead
         score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
-                        ovf_words, lists_per_q, cand_doc, cand_score, cand_count, after_doc, after_score, doc_base);
+                        ovf_words, lists_per_q, cand_doc, cand_score, cand_count, after_doc, after_score, doc_base, fin);
     }
 }
 
@@ -1196,10 +1271,10 @@ __global__ __launch_bounds__(THREADS) void srx_merge_wave_kernel(const int32_t *
                                                                  int32_t *__restrict__ out_doc,
                                                                  float *__restrict__ out_score,
                                                                  int32_t *__restrict__ out_count, int64_t out_row_stride,
-                                                                 int64_t out_cnt_stride, const int *__restrict__ gate) {
+                                                                 int64_t out_cnt_stride, const int *__restrict__ gate, int q0) {
     __shared__ MergeWaveShared MW[WAVES];
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int q = q0 + blockIdx.x * WAVES + (threadIdx.x >> 6);  // q0: first query this launch covers (the split ones of a search)
     if (q >= nq) return;
     if (gate != nullptr && *gate == 0) return;  // optional device-side switch (dense fallback pass)
     if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
@@ -1260,11 +1335,11 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
                                                             int64_t doc_base, int32_t *__restrict__ out_doc,
                                                             float *__restrict__ out_score,
                                                             int32_t *__restrict__ out_count, int64_t out_row_stride,
-                                                            int64_t out_cnt_stride, const int *__restrict__ gate) {
+                                                            int64_t out_cnt_stride, const int *__restrict__ gate, int q0) {
     __shared__ MergeShared M;
     const int tid = threadIdx.x;
-    const int q = blockIdx.x / n_groups;
-    const int g = blockIdx.x - q * n_groups;
+    const int q = q0 + blockIdx.x / n_groups;
+    const int g = blockIdx.x - (q - q0) * n_groups;
     if (q >= nq) return;
     if (gate != nullptr && *gate == 0) return;  // optional device-side switch (dense fallback pass)
     if (!gathered && in_count[(int64_t)q * n_lists * cnt_stride] < 0) return;  // tier 1 already wrote this query's final row
@@ -1310,38 +1385,9 @@ __global__ __launch_bounds__(THREADS) void srx_merge_kernel(const int32_t *__res
         if (tid == 0) out_count[(int64_t)q * n_groups + g] = (int)cnt;
         return;
     }
-    // rank: bitonic sort, descending on key64 = score bits : (0x7FFFFFFF - doc)
-    unsigned n = 1;
-    while (n < cnt) n <<= 1;
-    for (unsigned i = tid; i < n; i += THREADS)
-        M.sortkey[i] = i < cnt ? (((unsigned long long)M.tk.bits[i] << 32) | (0x7FFFFFFFu - (unsigned)M.tk.doc[i])) : 0ull;
-    __syncthreads();
-    for (unsigned size = 2; size <= n; size <<= 1) {
-        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-            for (unsigned i = tid; i < (n >> 1); i += THREADS) {
-                const unsigned pos = 2 * i - (i & (stride - 1));
-                const unsigned long long a = M.sortkey[pos], b = M.sortkey[pos + stride];
-                const bool desc = (pos & size) == 0;
-                if (desc ? (a < b) : (a > b)) {
-                    M.sortkey[pos] = b;
-                    M.sortkey[pos + stride] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const int64_t o = (int64_t)q * out_row_stride;  // final rows may live in a strided (packed) buffer
-    for (unsigned i = tid; i < (unsigned)k; i += THREADS) {
-        if (i < cnt) {
-            const unsigned long long x = M.sortkey[i];
-            out_doc[o + i] = (int32_t)(doc_base + (int64_t)(0x7FFFFFFFu - (unsigned)(x & 0xFFFFFFFFull)));
-            out_score[o + i] = __uint_as_float((unsigned)(x >> 32));
-        } else {
-            out_doc[o + i] = -1;
-            out_score[o + i] = 0.0f;
-        }
-    }
-    if (tid == 0) out_count[(int64_t)q * out_cnt_stride] = (int)cnt;
+    // rank: bitonic sort, descending on key64 = score bits : (0x7FFFFFFF - doc); final rows may live in a strided (packed) buffer
+    block_rank_emit(M.tk, M.sortkey, k, doc_base, out_doc + (int64_t)q * out_row_stride, out_score + (int64_t)q * out_row_stride,
+                    out_count + (int64_t)q * out_cnt_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1478,6 +1524,8 @@ struct srx_index {
     hipEvent_t *ev;   // PROF_SLOTS x PROF_EVENTS events, created lazily
     int ev_n;         // profiled calls recorded since the last srx_profile_read (<= PROF_SLOTS, then it wraps)
     int64_t ev_calls;
+    int *h_hint;      // pinned, device-mapped word: the tier-2 worklist length of a recent search (sizes the next tier-2 grid)
+    int *d_hint;      // its device address
 };
 
 SRX_API int srx_version(void) { return SRX_VERSION; }
@@ -1524,6 +1572,21 @@ SRX_API int srx_index_create(const srx_index_desc *d, srx_index **out) {
     ix->ev = nullptr;
     ix->ev_n = 0;
     ix->ev_calls = 0;
+    // 64 bytes of pinned host memory, created once with the handle (srx_search itself allocates nothing).  Not fatal when
+    // it cannot be had: the tier-2 grid then always has its full size.
+    ix->h_hint = nullptr;
+    ix->d_hint = nullptr;
+    if (hipSetDevice(d->device) == hipSuccess && hipHostMalloc((void **)&ix->h_hint, 64, hipHostMallocMapped) == hipSuccess) {
+        ix->h_hint[0] = -1;  // unknown
+        if (hipHostGetDevicePointer((void **)&ix->d_hint, ix->h_hint, 0) != hipSuccess) {
+            (void)hipHostFree(ix->h_hint);
+            ix->h_hint = nullptr;
+            ix->d_hint = nullptr;
+        }
+    } else {
+        ix->h_hint = nullptr;
+        (void)hipGetLastError();
+    }
     *out = ix;
     return SRX_OK;
 }
@@ -1534,6 +1597,7 @@ SRX_API void srx_index_destroy(srx_index *ix) {
         for (int i = 0; i < PROF_EVENTS * PROF_SLOTS; ++i) (void)hipEventDestroy(ix->ev[i]);
         delete[] ix->ev;
     }
+    if (ix->h_hint) (void)hipHostFree(ix->h_hint);
     delete ix;
 }
 
@@ -1672,27 +1736,40 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
         if (rc != SRX_OK) return rc;
     }
     if (prof) HIP_TRY(hipEventRecord(ev[1], stream));
-    // tier 2: flagged units, long queries, k > 128 -- a fixed grid drains the worklist tier 1 filled
-    const unsigned t2_grid = (unsigned)(blocks < 1024 ? blocks : 1024);
+    // tier 2: flagged units, long queries, k > 128 -- a persistent grid drains the worklist tier 1 filled.  Any grid size
+    // is correct; when a recent search of this index left the worklist empty (the hint word the kernel writes to pinned host
+    // memory, read here without synchronisation) a small grid spares an otherwise idle launch most of its dispatch time.
+    const int dbg2 = dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0);
+    const bool t2_everything = (dbg2 & 8) != 0 || k > W1_KMAX || ix->d.post16 == nullptr;  // tier 1 serves nothing: full grid
+    const int hint = ix->h_hint ? *(volatile int *)ix->h_hint : -1;
+    const int64_t t2_full = blocks < 1024 ? blocks : 1024;
+    const unsigned t2_grid = (unsigned)((hint == 0 && !t2_everything && t2_full > 128) ? 128 : t2_full);
+    Tier2Final fin;
+    fin.out_doc = out_doc; fin.out_score = out_score; fin.out_count = out_count; fin.ors = ors; fin.ocs = ocs; fin.hint = ix->d_hint;
     if (ix->d.val_type == SRX_VAL_F32)
         hipLaunchKernelGGL(srx_score_kernel<float>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0), ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base);
+                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q,
+                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base, fin);
     else
         hipLaunchKernelGGL(srx_score_kernel<__half>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0), ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base);
+                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q,
+                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base, fin);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
-    if (k <= W_KMAX && (int64_t)p.lists_per_q * k <= MW_CAP && p.lists_per_q <= 256 && !(dbg & 256))
-        hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cand_doc,
-                           cand_score, cand_count, nq, p.lists_per_q, k, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc,
-                           out_score, out_count, ors, ocs, (const int *)nullptr);
-    else
-        hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
-                           p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score,
-                           out_count, ors, ocs, (const int *)nullptr);
-    HIP_TRY(hipGetLastError());
+    // merge: only the SPLIT queries [n_whole, nq) have lists to merge (an unsplit query's final row was written by tier 1
+    // or, when it had work for tier 2, by tier 2)
+    const int nq_m = nq - p.n_whole;
+    if (nq_m > 0) {
+        if (k <= W_KMAX && (int64_t)p.lists_per_q * k <= MW_CAP && p.lists_per_q <= 256 && !(dbg & 256))
+            hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq_m + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cand_doc,
+                               cand_score, cand_count, nq, p.lists_per_q, k, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc,
+                               out_score, out_count, ors, ocs, (const int *)nullptr, p.n_whole);
+        else
+            hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq_m), dim3(THREADS), 0, stream, cand_doc, cand_score, cand_count, nq,
+                               p.lists_per_q, k, p.lists_per_q, 1, 1, 0, (int64_t)k, (int64_t)1, ix->d.doc_base, out_doc, out_score,
+                               out_count, ors, ocs, (const int *)nullptr, p.n_whole);
+        HIP_TRY(hipGetLastError());
+    }
     if (prof) {
         HIP_TRY(hipEventRecord(ev[3], stream));
         ++ix->ev_calls;
@@ -1795,7 +1872,7 @@ int srx_merge_impl(int32_t device, const int32_t *in_doc, const float *in_score,
         int32_t *oc = (int32_t *)(os + (int64_t)nq * groups * k);
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)((int64_t)nq * groups)), dim3(THREADS), 0, stream, cur_doc,
                            cur_score, cur_count, nq, lists, k, fan, groups, 0, lay, row_stride, cnt_stride, (int64_t)0, od, os,
-                           oc, (int64_t)k, (int64_t)1, gate);
+                           oc, (int64_t)k, (int64_t)1, gate, 0);
         HIP_TRY(hipGetLastError());
         lay = 0;
         row_stride = k;
@@ -1809,10 +1886,10 @@ int srx_merge_impl(int32_t device, const int32_t *in_doc, const float *in_score,
     if (k <= W_KMAX && (int64_t)lists * k <= MW_CAP && lists <= 256)
         hipLaunchKernelGGL(srx_merge_wave_kernel, dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(THREADS), 0, stream, cur_doc,
                            cur_score, cur_count, nq, lists, k, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score,
-                           out_count, ors, ocs, gate);
+                           out_count, ors, ocs, gate, 0);
     else
         hipLaunchKernelGGL(srx_merge_kernel, dim3((unsigned)nq), dim3(THREADS), 0, stream, cur_doc, cur_score, cur_count, nq,
-                           lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs, gate);
+                           lists, k, lists, 1, 1, lay, row_stride, cnt_stride, (int64_t)0, out_doc, out_score, out_count, ors, ocs, gate, 0);
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }

@@ -457,7 +457,8 @@ __device__ __forceinline__ void load_block(const int32_t *blk, __half, int (&d)[
 // The one rule both tiers apply: tier 1 (wave_kernel.hip) serves a query of nt > 0 terms iff this is false; tier 2
 // (sparse_rx.hip) then takes the whole query instead of the flagged units only.
 __device__ __forceinline__ bool tier1_cannot_serve(const IndexView &ix, int nt, int k, int tpu, int dbg) {
-    return nt > W_MAXT || k > W1_KMAX || (tpu << ix.tile_log2) > W_UNIT_MAX_DOCS || ix.post16 == nullptr || (dbg & 8) != 0;
+    return nt > W_MAXT || k > W1_KMAX || (tpu << ix.tile_log2) > W_UNIT_MAX_DOCS || ix.post16 == nullptr || (dbg & 8) != 0 ||
+           ix.vocab * (int64_t)(ix.n_tiles + 1) >= (1ll << 30);  // tier 1 addresses the skip table with 32-bit byte offsets
 }
 
 // one block of the compact copy: 4 unit-local docs + 4 values
@@ -472,6 +473,21 @@ __device__ __forceinline__ void load_block16(const int32_t *blk, __half, int (&d
     const srx_i4u a = gload_i4(blk);
     d[0] = (int)((unsigned)a.x & 0xFFFFu); d[1] = (int)((unsigned)a.x >> 16);
     d[2] = (int)((unsigned)a.y & 0xFFFFu); d[3] = (int)((unsigned)a.y >> 16);
+    const int bx = a.z, by = a.w;
+    const __half2 h0 = *reinterpret_cast<const __half2 *>(&bx), h1 = *reinterpret_cast<const __half2 *>(&by);
+    v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);
+}
+
+// the same block with the two id words left packed (tier 1 keeps them that way in registers)
+__device__ __forceinline__ void load_block16p(const int32_t *blk, float, unsigned (&d)[2], float (&v)[4]) {
+    const srx_i2u a = gload_i2(blk);
+    const srx_i4u b = gload_i4(blk + 2);
+    d[0] = (unsigned)a.x; d[1] = (unsigned)a.y;
+    v[0] = __int_as_float(b.x); v[1] = __int_as_float(b.y); v[2] = __int_as_float(b.z); v[3] = __int_as_float(b.w);
+}
+__device__ __forceinline__ void load_block16p(const int32_t *blk, __half, unsigned (&d)[2], float (&v)[4]) {
+    const srx_i4u a = gload_i4(blk);
+    d[0] = (unsigned)a.x; d[1] = (unsigned)a.y;
     const int bx = a.z, by = a.w;
     const __half2 h0 = *reinterpret_cast<const __half2 *>(&bx), h1 = *reinterpret_cast<const __half2 *>(&by);
     v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);

@@ -40,17 +40,16 @@
 
 namespace {
 
+enum { U_OK = 0, U_DENSE = 1, U_FULL = 2 };  // outcome of scoring one unit (see process)
+
 #ifndef SRX_W_WPE
 #define SRX_W_WPE W_WAVES_PER_EU
 #endif
+#ifndef SRX_W_CLEAR_BY_ADDRESS_UPTO
+#define SRX_W_CLEAR_BY_ADDRESS_UPTO 4  // units of up to this many slots per lane clear their bitmap words one by one (addresses recomputed from the ids), larger ones clear the whole bitmap with 8 wide stores
+#endif
 #ifndef SRX_W_DEPTH
 #define SRX_W_DEPTH 2  // register sets: units in flight + the one being scored
-#endif
-#ifndef SRX_W_PREFETCH
-#define SRX_W_PREFETCH 0  // 1: touch the lines of the unit after the one being loaded (see fetch).  Measured and left off: with the
-                          // touch's waits counted correctly the C3 batch takes 2.12 ms instead of 1.26 -- every line is requested
-                          // twice (touch, then the real load after the L1 has dropped it) and the L2 / fabric request rate, not
-                          // HBM latency, is what the kernel is up against (loads-only already streams at the HBM ceiling)
 #endif
 struct WaveShared2 {
     static constexpr int LCAP = W1_LCAP;
@@ -64,22 +63,33 @@ struct WaveShared2 {
     int ldoc[LCAP];
 };
 
-// d[rs] of lane src for a wave-uniform register index rs: a jump over v_readlane instructions
+// The unit-local doc ids stay PACKED in registers the way the compact copy stores them (two 16-bit ids per word: slot r
+// lives in half r & 1 of word r >> 1): a register set is W_R / 2 + W_R VGPRs instead of 2 W_R, which is what pays for the
+// third set in flight (SRX_W_DEPTH).  Pass 1 reads the halves with shifts that cost what the unpacked form's did.
+constexpr int W_RP = W_R / 2;
+__device__ __forceinline__ unsigned slot_id(const unsigned (&dp)[W_RP], int r) {  // r: compile-time constant after unrolling
+    return (r & 1) ? dp[r >> 1] >> 16 : dp[r >> 1] & 0xFFFFu;
+}
+// id of slot rs of lane src for a wave-uniform slot index rs: a jump over v_readlane instructions (one per word)
 template <int NR>
-__device__ __forceinline__ int lane_reg(const int (&d)[W_R], int rs, int src) {
-    switch (rs) {
+__device__ __forceinline__ int lane_reg(const unsigned (&dp)[W_RP], int rs, int src) {
+    unsigned w;
+    switch (rs >> 1) {
 #define SRX_CASE(i) \
     case i:         \
-        return __builtin_amdgcn_readlane(d[(i) < NR ? (i) : 0], src);
-        SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7) SRX_CASE(8) SRX_CASE(9) SRX_CASE(10)
-        SRX_CASE(11) SRX_CASE(12) SRX_CASE(13) SRX_CASE(14) SRX_CASE(15)
+        w = (unsigned)__builtin_amdgcn_readlane((int)dp[(i) < NR / 2 ? (i) : 0], src); \
+        break;
+        SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
 #undef SRX_CASE
         default:
-            return __builtin_amdgcn_readlane(d[0], src);
+            w = (unsigned)__builtin_amdgcn_readlane((int)dp[0], src);
     }
+    return (int)((rs & 1) ? w >> 16 : w & 0xFFFFu);
 }
 
-template <typename VT>
+// DBG: the ablation build of the same kernel (bench.py --debug: timing experiments with WRONG results).  The shipped instance
+// (DBG = false) carries none of those tests in its unit loop.
+template <typename VT, bool DBG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE))) void srx_wave_kernel(const srx_wave_launch a) {
     __shared__ WaveShared2 S;
     constexpr int BW = CompactWords<VT>::value;  // tier 1 streams the compact copy (16-bit unit-local docs)
@@ -98,6 +108,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             a.cand_count[list] = 0;
             if (nt > 0) a.work[1 + atomicAdd(&a.work[0], 1)] = (int)blockIdx.x;
         }
+        if (nt == 0 && nsq == 1 && a.out_doc != nullptr) {  // an unsplit query without terms: nobody else writes its (empty) row
+            for (int i = lane; i < k; i += 64) {
+                a.out_doc[(int64_t)q * a.out_row_stride + i] = -1;
+                a.out_score[(int64_t)q * a.out_row_stride + i] = 0.0f;
+            }
+            if (lane == 0) {
+                a.out_count[(int64_t)q * a.out_cnt_stride] = 0;
+                a.cand_count[list] = -1;
+            }
+        }
         return;
     }
     const int su_lo = (int)(((int64_t)a.n_super * split) / nsq);
@@ -107,7 +127,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
     for (int i = lane; i < W_BM_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     wsync();
     WaveTopk tk = {0u, 0u};  // wave-uniform lazy top-k list state
-    int sink = 0;            // debug only
+    int sink = 0;            // DBG only
+    const int dbg = DBG ? a.dbg : 0;
 #ifdef SRX_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
     unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -126,12 +147,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         const int jl = lane & (LPT - 1);
         const bool has_term = tslot < nt;
         int64_t tblk = 0;
-        const int32_t *skip_row = ix.tile_skip;
+        unsigned skip_boff = 0;  // BYTE offset of my term's skip row (the table is < 4 GiB: tier1_cannot_serve): one VGPR, and the
+                                 // loads take the table's base from SGPRs (global_load ... v_off, s[base])
         float my_idf = 0.f, my_qw = 0.f;
         if (has_term) {
             const int term = a.q_term[t0 + tslot];
             tblk = ix.term_ptr[term] >> 2;
-            skip_row = ix.tile_skip + (int64_t)term * row;
+            skip_boff = ((unsigned)term * (unsigned)row) << 2;
             my_idf = ix.idf[term];
             my_qw = a.q_weight[t0 + tslot];
         }
@@ -157,69 +179,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         // masked where the run length is formed) and consumed SRX_W_DEPTH + 1 fetches later: a load inside a divergent
         // branch made the compiler finish it on the spot with s_waitcnt vmcnt(0), which also drained the posting loads of
         // the next unit issued just before it -- the wave then had nothing in flight while it scored.
-        auto bound = [&](int j) __attribute__((always_inline)) -> int { return gload_i32(skip_row + min(j * tpu, ix.n_tiles)); };
+        auto bound = [&](int j) __attribute__((always_inline)) -> int {
+            return gload_i32(reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ix.tile_skip) +
+                                                               (size_t)(skip_boff + ((unsigned)min(j * tpu, ix.n_tiles) << 2))));
+        };
 
         // Issue the loads of my term's run [lo, lo + len) (in blocks) of the unit: register r = 4 s + i holds posting i
         // of block s * LPT + jl.  Always exactly 2 * W_R / 4 loads, no branches (idle steps read a sentinel block
         // through the other pointer, same immediate offset), so that the compiler can wait for THIS unit's data with
         // a counted s_waitcnt vmcnt(N) while the NEXT unit's loads stay in flight.
-        auto issue = [&](int lo, int len, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
+        auto issue = [&](int lo, int len, unsigned (&d)[W_RP], float (&v)[W_R]) __attribute__((always_inline)) {
             const int32_t *p = tpost + (int64_t)lo * BW;
             const int rem = len - jl;  // step s is mine iff s * LPT < rem
 #pragma unroll
             for (int s4 = 0; s4 < W_R / 4; ++s4) {
                 const int off = (s4 << LPT_LOG2) * BW;
                 const bool ok = (s4 << LPT_LOG2) < rem;
-                int dd[4];
+                unsigned dd[2];
                 float vv[4];
-                load_block16((ok ? p : zblk) + off, VT(), dd, vv);  // idle: sentinel block lane + s4 * LPT (SRX_BLOCK_PAD covers it)
+                load_block16p((ok ? p : zblk) + off, VT(), dd, vv);  // idle: sentinel block lane + s4 * LPT (SRX_BLOCK_PAD covers it)
+                d[2 * s4] = dd[0];
+                d[2 * s4 + 1] = dd[1];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d[4 * s4 + c] = dd[c];
-                    v[4 * s4 + c] = vv[c];
-                }
+                for (int c = 0; c < 4; ++c) v[4 * s4 + c] = vv[c];
             }
         };
 
-        // Score one unit from registers (the first NR of them hold postings).  false -> the unit goes to tier 2
-        // (nothing emitted).
-        auto process = [&](auto nrc, int ubase, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> bool {  // d = unit-local ids, ubase = the unit's first doc
+        // Score one unit from registers (the first NR of them hold postings).  U_OK: done.  U_DENSE: the unit goes to tier 2
+        // (nothing emitted).  U_FULL: the lazy list cannot take this unit's candidates -- nothing of the unit stays in the
+        // list, the caller shrinks the list OUTSIDE the pipelined loop and comes back to this unit.  (The selection is a
+        // function call: inside the loop it would have to keep every register set in flight alive across the call, which
+        // cost the loop ~35 VGPRs and with them the third set.)
+        auto process = [&](auto nrc, int ubase, unsigned (&d)[W_RP], float (&v)[W_R]) __attribute__((always_inline)) -> int {  // d = packed unit-local ids, ubase = the unit's first doc
             constexpr int NR = decltype(nrc)::value;
-            if (tk.count > (unsigned)(WaveShared2::LCAP - 64 - W_DUPCAP)) {  // uniform, rare: room for this unit's multi-term docs
-                tk.tau = uniu(wave_list_select(S, tk.count, k));
-                tk.count = (unsigned)k;
-            }
-            // ---- pass 1: doc bits ----
-            unsigned adr[NR], t[NR];  // t[r] != 0: posting r found its doc's bit already set (an earlier posting matched the doc)
+            const unsigned count0 = tk.count;
+            if (count0 + (unsigned)W_DUPCAP + 1u > (unsigned)WaveShared2::LCAP) return U_FULL;  // uniform, rare: room for this unit's multi-term docs
+            // ---- pass 1: doc bits.  Every slot ORs its bit into the bitmap word of its id; the word that comes back tells
+            //      whether an earlier posting (another term's) matched the same doc: fm = the lane's slots that found their bit
+            //      already set.  Nothing but the returned words is kept across the LDS round trip (the bit position is read
+            //      again from the id register with v_bfe), and nothing is kept for the clean-up below ----
+            unsigned old[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                adr[r] = ((unsigned)d[r] >> 3) & (unsigned)((W_BM_WORDS - 1) << 2);             // byte offset of word (doc >> 5) & 2047
+                const unsigned w = d[r >> 1];  // id = half r & 1 of the word
+                const unsigned adr = (w >> ((r & 1) ? 19 : 3)) & (unsigned)((W_BM_WORDS - 1) << 2);  // byte offset of word (id >> 5) & 2047
                 unsigned one;  // min(value bits, 1): 0 for a value of exactly +0 (v_min_u32; the compiler's own form is cmp + cndmask)
                 asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(__float_as_uint(v[r])));
-                const unsigned bit = one << ((unsigned)d[r] & 31u);
-                t[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]), bit) & bit;
+                const unsigned bit = one << (((r & 1) ? w >> 16 : w) & 31u);
+                old[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr), bit);
             }
-            unsigned acc = 0;
+            unsigned fm = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) acc |= t[r];
+            for (int r = 0; r < NR; ++r) {  // a sentinel's word is all zero (a word of its own per lane, value 0 sets no bit)
+                const unsigned w = d[r >> 1];
+                fm |= __builtin_amdgcn_ubfe(old[r], ((r & 1) ? w >> 16 : w) & 31u, 1u) << r;
+            }
             bool dense = false;
-            const bool anydup = __ballot(acc != 0u) != 0ull;
+            const bool anydup = __ballot(fm != 0u) != 0ull;
             STAMP(2);  // wait for the unit's postings + pass 1
             CNT(0);
-            if (anydup && !(a.dbg & 1)) {  // uniform: some doc of this unit is matched by several terms (~3 units in 4 on C3)
+            // ---- the bitmap goes back to all zero: 8 wide stores (no address is kept per slot; a unit with one load step
+            //      clears its four words by address) ----
+            if constexpr (NR <= SRX_W_CLEAR_BY_ADDRESS_UPTO) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const unsigned w = d[r >> 1];
+                    *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + ((w >> ((r & 1) ? 19 : 3)) & (unsigned)((W_BM_WORDS - 1) << 2))) = 0u;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < W_BM_WORDS / 256; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            STAMP(4);  // restore
+            if (anydup && !(dbg & 1)) {  // uniform: some doc of this unit is matched by several terms (~3 units in 4 on C3)
                 CNT(1);
                 // Lanes with a flagged posting (typically one or two) are visited one after the other: fm = the lane's
                 // flagged slots; the doc of its lowest flagged slot is broadcast, every lane picks up and blanks its
                 // posting of that doc (a doc occurs at most once per term, hence at most once per lane; sentinels carry
-                // local ids no real posting has), and the contributions are added in ascending lane order = the query's term order.
-                unsigned fm = 0;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    unsigned one;
-                    asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(t[r]));
-                    fm |= one << r;
-                }
-                const unsigned count0 = tk.count;
+                // local ids no real posting has; a posting whose stored value is exactly 0 may be flagged too: it adds
+                // nothing), and the contributions are added in ascending lane order = the query's term order.
                 unsigned n_res = 0;
                 unsigned long long m = __ballot(fm != 0u);
                 while (m != 0ull) {  // uniform loop: about two docs per such unit on C3
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                     const int rs = __ffs((int)fms) - 1;                 // uniform: lane src's lowest flagged slot
                     const int dd = lane_reg<NR>(d, rs, src);            // its doc, wave-uniform
                     CNT(2);
-                    if (a.dbg & 512) {  // timing experiment: locate the docs only
+                    if (dbg & 512) {  // timing experiment: locate the docs only
                         sink += dd;
                         fm = (lane == src) ? (fm & (fm - 1u)) : fm;
                         m = __ballot(fm != 0u);
@@ -237,7 +275,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                     float myv = 0.0f;
 #pragma unroll
                     for (int r2 = 0; r2 < NR; ++r2) {
-                        const bool hit = d[r2] == dd;
+                        const bool hit = (int)slot_id(d, r2) == dd;
                         myv = hit ? v[r2] : myv;
                         v[r2] = hit ? 0.0f : v[r2];
                     }
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                         mm &= mm - 1ull;
                     }
                     const unsigned b = __float_as_uint(sum);
-                    if (sum > 0.0f && b >= tk.tau && !(a.dbg & 1024)) {  // uniform; room for W_DUPCAP entries was made above
+                    if (sum > 0.0f && b >= tk.tau && !(dbg & 1024)) {  // uniform; room for W_DUPCAP entries was made above
                         if (lane == 0) {
                             S.lbits[tk.count] = b;
                             S.ldoc[tk.count] = ubase + dd;
@@ -267,12 +305,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 }
             }
             STAMP(3);  // multi-term docs
-            // ---- clear the bitmap words again ----
-#pragma unroll
-            for (int r = 0; r < NR; ++r) *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]) = 0u;
-            STAMP(4);  // restore
-            if (dense) return false;
-            if (a.dbg & 2) return true;  // timing experiment: no candidate screening (results are wrong)
+            if (dense) return U_DENSE;
+            if (dbg & 2) return U_OK;  // timing experiment: no candidate screening (results are wrong)
             // ---- single-term docs.  Almost no posting can beat tau once the list has warmed up, so a conservative
             //      per-lane threshold on the stored value (vthr <= the smallest v whose contribution could reach tau, and
             //      > 0 so that blanked registers and sentinels never pass) screens them with one compare; the exact fp32
@@ -297,12 +331,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                     if (__ballot(pass) != 0ull) {
                         const float c = 0.0f + (v[r] * my_idf) * my_qw;
                         const unsigned b = __float_as_uint(c);
-                        wave_append(S, tk, k, pass && c > 0.0f && b >= tk.tau, b, ubase + d[r]);
+                        const bool cand = pass && c > 0.0f && b >= tk.tau;
+                        const unsigned long long m2 = __ballot(cand);
+                        const unsigned n2 = (unsigned)__popcll(m2);
+                        if (tk.count + n2 > (unsigned)WaveShared2::LCAP) {  // uniform: no room -- the unit is redone after a selection
+                            tk.count = count0;
+                            return U_FULL;
+                        }
+                        if (cand) {
+                            const unsigned pz = tk.count + lane_rank(m2);
+                            S.lbits[pz] = b;
+                            S.ldoc[pz] = ubase + (int)slot_id(d, r);
+                        }
+                        tk.count += n2;
                     }
                 }
             }
-            STAMP(6);  // candidates (appends, selections)
-            return true;
+            STAMP(6);  // candidates (appends)
+            return U_OK;
         };
 
         auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
@@ -314,107 +360,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         //      loads of units u+1 .. u+DEPTH-1 are in flight (a wave has no other way to keep memory requests outstanding:
         //      with one unit ahead the data arrives long before the unit before it has been scored, and nothing is in
         //      flight for the rest of that time) ----
-        // score unit su held in (d, v) with run length lenc (blocks)
-        auto score = [&](int su, int lenc, int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) {
-            if (a.dbg & 4) {  // timing experiment: loads only (results are wrong)
+        // score unit su held in (d, v); steps = the load steps that hold postings (0: nothing to do, W_R / 4 + 1: some term's
+        // run does not fit the registers -> tier 2).  Wave-uniform, decided when the loads were issued: no per-lane run
+        // length has to stay in a register while the unit is in flight.
+        // returns true when the list was full: the unit has NOT been scored
+        auto score = [&](int su, int steps, unsigned (&d)[W_RP], float (&v)[W_R]) __attribute__((always_inline)) -> bool {
+            if (dbg & 4) {  // timing experiment: loads only (results are wrong)
 #pragma unroll
-                for (int r = 0; r < W_R; ++r) sink += d[r] ^ (int)__float_as_uint(v[r]);
-            } else if (__ballot(lenc > (W_R / 4) * LPT) != 0ull) {
+                for (int r = 0; r < W_R; ++r) sink += (int)(d[r >> 1] ^ __float_as_uint(v[r]));
+            } else if (steps > W_R / 4) {
                 flag_tier2(su);
-            } else if (__ballot(lenc > 0) != 0ull) {
-                bool fine;
-                bool done = false;
+            } else if (steps > 0) {
+                int rc;
                 const int ubase = (su * tpu) << ix.tile_log2;
-                if constexpr (W_R > 12) {
-                    if (__ballot(lenc - jl > 3 * LPT) != 0ull) {  // uniform: the fourth load step holds postings
-                        fine = process(IntC<16>{}, ubase, d, v);
-                        done = true;
-                    }
-                }
-                if constexpr (W_R > 8) {
-                    if (!done && __ballot(lenc - jl > 2 * LPT) != 0ull) {  // uniform: the third load step holds postings
-                        fine = process(IntC<12>{}, ubase, d, v);
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    if (__ballot(lenc - jl > LPT) != 0ull)
-                        fine = process(IntC<8>{}, ubase, d, v);
-                    else
-                        fine = process(IntC<4>{}, ubase, d, v);
-                }
-                if (!fine) flag_tier2(su);
+                if (W_R > 12 && steps == 4)
+                    rc = process(IntC<(W_R > 12 ? 16 : 4)>{}, ubase, d, v);
+                else if (W_R > 8 && steps == 3)
+                    rc = process(IntC<(W_R > 8 ? 12 : 4)>{}, ubase, d, v);
+                else if (steps == 2)
+                    rc = process(IntC<8>{}, ubase, d, v);
+                else
+                    rc = process(IntC<4>{}, ubase, d, v);
+                if (rc == U_DENSE) flag_tier2(su);
+                return rc == U_FULL;
             }
+            return false;
         };
-        // issue unit su's loads into (d, v); returns its run length (0 past the end; a run that does not fit loads nothing)
-#if SRX_W_PREFETCH
-        int pf_val = 0;
-#endif
-        constexpr int NBQ = SRX_W_DEPTH + 2 + SRX_W_PREFETCH;  // the touch looks one unit further ahead
+        // issue unit su's loads into (d, v); returns its step count (see score; a run that does not fit loads nothing)
+        constexpr int NBQ = SRX_W_DEPTH + 2;
         int bq[NBQ];  // bq[i] = boundary (next unit to issue) + i, in padded postings
         int su_issue = su_lo;
-#pragma unroll
-        for (int i = 0; i < NBQ; ++i) bq[i] = bound(su_lo + i);
-        auto fetch = [&](int (&d)[W_R], float (&v)[W_R]) __attribute__((always_inline)) -> int {
+        auto fetch = [&](unsigned (&d)[W_RP], float (&v)[W_R]) __attribute__((always_inline)) -> int {
             const int len = (has_term && su_issue < su_hi) ? (bq[1] - bq[0]) >> 2 : 0;  // blocks
-            const bool fit = __ballot(len > (W_R / 4) * LPT) == 0ull;  // uniform: every term's run fits the steps
+            int steps = 0;  // uniform
+#pragma unroll
+            for (int s4 = 0; s4 <= W_R / 4; ++s4) steps += (__ballot(len > (s4 << LPT_LOG2)) != 0ull) ? 1 : 0;
             STAMP(0);  // loop overhead / previous tail
-#if SRX_W_PREFETCH
-            {
-                // Touch the 128-byte lines of the unit AFTER the one loaded below (one dword per line, lane jl takes line jl of
-                // my term's run; PF_STRIDE blocks per line): those lines are on their way from HBM to L2 while this unit's
-                // loads are in flight, so the wave keeps two units' worth of requests outstanding with ONE more register --
-                // the kernel is limited by bytes in flight (16 waves per CU x one unit each), and a third register set costs a
-                // wave per SIMD.  The touch is issued BEFORE this unit's loads and its value is consumed at the next fetch:
-                // loads return in order, so a wait for a touch issued AFTER a unit's loads is a wait for that whole unit.
-                sink ^= pf_val;  // the touch issued one fetch ago, older than that fetch's posting loads (a counted wait)
-                constexpr int PF_STRIDE = 128 / (BW * 4);  // whole blocks per line (4 for fp32 values, 5 for fp16)
-                const int nlen = (has_term && su_issue + 1 < su_hi) ? (bq[2] - bq[1]) >> 2 : 0;
-                const int pb = min(PF_STRIDE * jl, nlen - 1);  // the lane after the last whole line takes the run's last block
-                const bool pok = PF_STRIDE * jl < nlen + PF_STRIDE - 1;
-                // lanes with nothing to touch re-read block 0 of their term (valid memory, already cached): no branch, no
-                // second pointer
-                pf_val = gload_i32(tpost + (int64_t)((pok ? (bq[1] >> 2) + pb : jl) - jl) * BW);
-                __builtin_amdgcn_sched_barrier(0);  // the scheduler must not move the touch behind the posting loads
-            }
-#endif
-            issue(bq[0] >> 2, fit ? len : 0, d, v);
+            issue(bq[0] >> 2, steps > W_R / 4 ? 0 : len, d, v);
             STAMP(1);  // issue
 #pragma unroll
             for (int i = 0; i < NBQ - 1; ++i) bq[i] = bq[i + 1];
             ++su_issue;
             bq[NBQ - 1] = bound(su_issue + NBQ - 1);  // needed NBQ - 2 fetches from now (clamped to the row end)
-            return len;
+            return steps;
         };
-#if SRX_W_DEPTH == 2
-        int dA[W_R], dB[W_R];
-        float vA[W_R], vB[W_R];
-        int lenA = fetch(dA, vA), lenB = 0;
-        for (int su = su_lo; su < su_hi; su += 2) {
-            lenB = fetch(dB, vB);
-            score(su, lenA, dA, vA);
-            if (su + 1 < su_hi) {
-                lenA = fetch(dA, vA);
-                score(su + 1, lenB, dB, vB);
+        // DEPTH register sets rotate: set j holds unit su + j when the round starts; before a unit is scored the loads of the
+        // unit DEPTH - 1 ahead of it are issued into the set that was scored last (a fetch past the end issues sentinel loads only).
+        // The pipeline is (re)started at unit su_start: once per item, and again after every selection of the lazy list --
+        // the units in flight at that moment are fetched a second time (L2 hits), a few times per query while the threshold
+        // warms up and hardly ever after.
+        constexpr int DEPTH = SRX_W_DEPTH;
+        int su_start = su_lo;
+        for (;;) {
+            su_issue = su_start;
+#pragma unroll
+            for (int i = 0; i < NBQ; ++i) bq[i] = bound(su_start + i);
+            unsigned dS[DEPTH][W_RP];
+            float vS[DEPTH][W_R];
+            int st[DEPTH];  // uniform: load steps of the unit in set j (see score)
+#pragma unroll
+            for (int j = 0; j < DEPTH - 1; ++j) st[j] = fetch(dS[j], vS[j]);
+            st[DEPTH - 1] = 0;
+            int su_full = -1;  // uniform: the unit that found the list full
+            for (int su = su_start; su < su_hi && su_full < 0; su += DEPTH) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) {
+                    if ((j == 0 || su + j < su_hi) && su_full < 0) {  // uniform
+                        st[(j + DEPTH - 1) % DEPTH] = fetch(dS[(j + DEPTH - 1) % DEPTH], vS[(j + DEPTH - 1) % DEPTH]);
+                        if (score(su + j, st[j], dS[j], vS[j])) su_full = su + j;
+                    }
+                }
+            }
+            if (su_full < 0) break;
+            // ---- no register set is live here: shrink the list to its k best (tau rises) and redo unit su_full.  A unit that
+            //      does not fit next to a list of k entries either goes to tier 2 ----
+            if (tk.count > (unsigned)k) {
+                tk.tau = uniu(wave_list_select(S, tk.count, k));
+                tk.count = (unsigned)k;
+                su_start = su_full;
+            } else {
+                flag_tier2(su_full);
+                su_start = su_full + 1;
             }
         }
-#else
-        int dA[W_R], dB[W_R], dC[W_R];
-        float vA[W_R], vB[W_R], vC[W_R];
-        int lenA = fetch(dA, vA), lenB = fetch(dB, vB), lenC = 0;
-        for (int su = su_lo; su < su_hi; su += 3) {
-            lenC = fetch(dC, vC);
-            score(su, lenA, dA, vA);
-            if (su + 1 < su_hi) {
-                lenA = fetch(dA, vA);
-                score(su + 1, lenB, dB, vB);
-            }
-            if (su + 2 < su_hi) {
-                lenB = fetch(dB, vB);
-                score(su + 2, lenC, dC, vC);
-            }
-        }
-#endif
     };
     switch (6 - lg) {
         case 0: run(IntC<0>{}); break;
@@ -425,10 +453,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         case 5: run(IntC<5>{}); break;
         default: run(IntC<6>{}); break;
     }
-    if ((a.dbg & (4 | 512)) && sink == 0x7F123457) a.cand_count[list] = sink;  // keeps the loads of the timing experiment alive
-    if (a.nq < 0 && sink == 0x7F123457) a.cand_count[list] = sink;               // never true (nq >= 0): keeps the touch loads alive
+    if ((dbg & (4 | 512)) && sink == 0x7F123457) a.cand_count[list] = sink;  // keeps the loads of the timing experiment alive
     unsigned count = tk.count;
-    if (a.dbg & 32) count = 0;  // timing experiment: no final selection / ranking
+    if (dbg & 32) count = 0;  // timing experiment: no final selection / ranking
     if (count > (unsigned)k) {
         wave_list_select(S, count, k);
         count = (unsigned)k;
@@ -467,10 +494,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
 
 int srx_launch_wave_kernel(const srx_wave_launch &a, int val_type, int64_t blocks, hipStream_t stream) {
     if (blocks <= 0) return SRX_OK;
-    if (val_type == SRX_VAL_F32)
-        hipLaunchKernelGGL(srx_wave_kernel<float>, dim3((unsigned)blocks), dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL(srx_wave_kernel<__half>, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    const bool ablate = (a.dbg & (1 | 2 | 4 | 32 | 512 | 1024)) != 0;  // timing experiments: the DBG instance
+    if (val_type == SRX_VAL_F32) {
+        if (ablate)
+            hipLaunchKernelGGL((srx_wave_kernel<float, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((srx_wave_kernel<float, false>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    } else {
+        if (ablate)
+            hipLaunchKernelGGL((srx_wave_kernel<__half, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((srx_wave_kernel<__half, false>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return SRX_OK;
 }

@@ -238,6 +238,21 @@ class DenseF32Index:
                     self.emb[lo: lo + chunk.shape[0], : self.dim] = torch.from_numpy(chunk).to(self.device)
         self.doc_base = int(doc_base)
         self._ws = None
+        self._max_norm = None
+
+    def max_row_norm(self) -> float:
+        """Largest Euclidean row norm (fp64 accumulation), computed once on the device from the resident matrix in row
+        chunks of <= 64 MB -- never a host-side temporary of the (possibly memory-mapped) matrix."""
+        if self._max_norm is None:
+            torch = _torch()
+            rows = max(1, (64 << 20) // (4 * self.dim_pad))
+            best = 0.0
+            with torch.cuda.device(self.device):
+                for lo in range(0, self.n_docs, rows):
+                    c = self.emb[lo: lo + rows].double()
+                    best = max(best, float((c * c).sum(dim=1).max().item()))
+            self._max_norm = best ** 0.5
+        return self._max_norm
 
     def search_device(self, queries, k: int, score_offset: float = 0.0):
         """Top-k of (score + score_offset) > 0 per query (include/sparse_rx.h); the returned scores carry the offset."""

@@ -547,8 +547,10 @@ class DeviceIndex:
         return {"wave_ms": ms[0], "block_ms": ms[1], "merge_ms": ms[2], "total_ms": ms[3], "calls": n}
 
     def device_bytes(self) -> int:
-        ts = [self.term_ptr, self.post, self.tile_skip, self.idf] + ([self.term_bound] if self.term_bound is not None else [])
-        return sum(t.numel() * t.element_size() for t in ts)
+        """Everything this shard keeps resident: both copies of the postings (canonical 8 / 6 bytes per posting + the
+        compact tier-1 copy 6 / 4), the skip table, idf and the bound tables."""
+        ts = [self.term_ptr, self.post, self.post16, self.tile_skip, self.idf, self.term_bound, self.fine_bound]
+        return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

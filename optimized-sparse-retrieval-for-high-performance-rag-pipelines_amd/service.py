@@ -182,18 +182,19 @@ class RetrievalService:
         if e.ndim != 2 or (self.doc_ids and e.shape[0] != len(self.doc_ids)):
             raise ValueError("embeddings must be [n_docs, dim] with one row per document")
         self.embedding_index = e
-        self._emb_maxnorm = float(np.sqrt((e.astype(np.float64) ** 2).sum(axis=1).max())) if e.size else 0.0
-        self._dense = DenseF32Index(e, device=self.device)
+        self._dense = DenseF32Index(e, device=self.device)  # streams a memory map to the device in <= 64 MB chunks
 
     def search_by_vector(self, query_vector: np.ndarray, k: int = 10, min_score: float = 0.0) -> List[Dict]:
         """retrieval.py:402-436: ``np.dot(embedding_index, query_vector)`` + top-k on the GPU (``srx_dense_search_f32``),
         the ``min_score`` cut and the ``[{"doc_id", "score"}]`` result as in the reference.
 
-        The engine ranks positive values only.  For ``min_score > 0`` that is all the reference can return either.  For
-        ``min_score <= 0`` (the default is 0.0: rows with a score of exactly 0 count, and negative thresholds admit
-        negative scores, :425-427) the scores are shifted by a bound on the largest |score| so that every doc is
-        rankable; the k returned rows are then re-scored on the host with ``np.dot`` (fp32, the reference's own
-        expression) and re-ranked, so the shift never shows in the result."""
+        The engine ranks positive values only, so the unshifted search runs first: when it fills all k rows they are all
+        > 0 >= ``min_score`` and ARE the reference's top-k -- the common case, exact, no host work.  Only when fewer than k
+        docs score above 0 and ``min_score <= 0`` (the default 0.0 admits rows with a score of exactly 0, negative
+        thresholds admit negative scores, :425-427) a second pass shifts the scores by a bound on the largest |score| so
+        that every doc is rankable; its k rows are re-scored on the host with ``np.dot`` (fp32, the reference's own
+        expression) and re-ranked, so the shift never shows in the result.  The shift coarsens that pass's ranking to
+        ulp(offset): docs whose true scores differ by less can swap places at the k-th boundary (scores <= 0 only)."""
         if getattr(self, "_dense", None) is None and self.embedding_path and os.path.exists(str(self.embedding_path)) and self.doc_ids:
             n = len(self.doc_ids)
             dim = os.path.getsize(str(self.embedding_path)) // (n * 4)  # retrieval.py:324-328
@@ -202,13 +203,13 @@ class RetrievalService:
             raise ValueError("No embedding index available")
         q = np.asarray(query_vector, dtype=np.float32)
         kk = max(1, min(int(k), self._dense.n_docs))
-        if min_score > 0:
-            d, s, n = self._dense.search(q, kk)
+        d, s, n = self._dense.search(q, kk)
+        if min_score > 0 or int(n[0]) == kk:
             idx, sc = d[0, : int(n[0])].astype(np.int64), s[0, : int(n[0])]
         else:
             # |score| <= |q|_2 * max row norm (Cauchy-Schwarz): the smallest shift that makes every doc rankable keeps
             # the most fp32 resolution for the ranking (the shifted scores are only used to pick the k rows)
-            bound = float(np.linalg.norm(q.astype(np.float64))) * self._emb_maxnorm
+            bound = float(np.linalg.norm(q.astype(np.float64))) * self._dense.max_row_norm()
             offset = bound * 1.001 + 1e-30
             d, s, n = self._dense.search(q, kk, score_offset=offset)
             idx = d[0, : int(n[0])].astype(np.int64)

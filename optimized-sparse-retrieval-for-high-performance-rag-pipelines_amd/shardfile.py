@@ -14,9 +14,10 @@ Reading validates the header against itself BEFORE anything reaches the GPU -- t
 dims and receive raw pointers without sizes, so a damaged or mismatched header must become a ``ValueError`` here, never
 an out-of-bounds device read: every array length against the dims (term_ptr V+1, idf V, (n_blocks + pad) blocks of 8 or
 6 words, skip table V x (n_tiles+1), bounds V x 4 / V x 14), term_ptr a non-decreasing table of multiples of 4 from 0 to
-4 n_blocks, offsets non-negative, aligned and non-overlapping; with ``verify`` also the array checksums, doc ids inside
-[-2017, n_docs) (negative = sentinel) and the skip rows (non-decreasing, block-aligned at unit boundaries, ending at the term's
-padded posting count).  Loading memory-maps the file and streams each array to the GPU in
+4 n_blocks, the skip rows (non-decreasing, block-aligned at unit boundaries, ending at the term's padded posting count),
+offsets non-negative, aligned and non-overlapping.  With ``verify`` (default) also the array checksums and the O(nnz) scan
+that every doc id lies inside [-2017, n_docs) (negative = sentinel); ``verify=False`` TRUSTS the posting bytes themselves
+(a doc id outside the shard would index the kernels' LDS tables out of range).  Loading memory-maps the file and streams each array to the GPU in
 bounded chunks (host memory stays small at 10^9 postings); nothing in the file is executed."""
 import json
 import os
@@ -155,6 +156,12 @@ def read_shard_file(path: str, verify: bool = True):
     tp = np.asarray(out["term_ptr"])
     if int(tp[0]) != 0 or int(tp[-1]) != 4 * n_blocks or np.any(np.diff(tp) < 0) or np.any(tp & 3):
         raise ValueError(f"{path}: term_ptr is not a non-decreasing table of block-aligned positions from 0 to 4 * n_blocks = {4 * n_blocks}")
+    # tile_skip rows index `post` from inside the kernels: their structure is checked on every load, O(vocab * n_tiles) like
+    # the term_ptr check above (only the O(nnz) doc-id scan and the checksums are left to `verify`)
+    ts = np.asarray(out["tile_skip"]).reshape(vocab, n_tiles + 1)
+    if (np.any(ts[:, 0] != 0) or np.any(np.diff(ts, axis=1) < 0) or np.any(ts[:, -1].astype(np.int64) != np.diff(tp))
+            or np.any(ts[:, ::unit_tiles] & 3)):
+        raise ValueError(f"{path}: tile_skip rows are not non-decreasing, block-aligned at unit boundaries and ending at the term's padded posting count")
     if verify:
         for name, e in entries.items():
             if _crc(np.asarray(out[name])) != int(e.get("crc32", -1)):
@@ -165,8 +172,4 @@ def read_shard_file(path: str, verify: bool = True):
             docs = np.asarray(blocks[i: i + chunk, :4])
             if docs.size and (int(docs.min()) < -1 - 32 * 63 or int(docs.max()) >= n_docs):
                 raise ValueError(f"{path}: post holds doc ids outside [-2017, {n_docs})")
-        ts = np.asarray(out["tile_skip"]).reshape(vocab, n_tiles + 1)
-        if (np.any(ts[:, 0] != 0) or np.any(np.diff(ts, axis=1) < 0) or np.any(ts[:, -1].astype(np.int64) != np.diff(tp))
-                or np.any(ts[:, ::unit_tiles] & 3)):
-            raise ValueError(f"{path}: tile_skip rows are not non-decreasing, block-aligned at unit boundaries and ending at the term's padded posting count")
     return meta, out
