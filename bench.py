@@ -170,6 +170,38 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def emulated_bound_check(ix, host_csr, idf_np, avgdl, q_host, k, mode, gpu_rows, n_check=N_CHECK):
+    """--emulate-world rehearsals: the shard searches with the score bounds it would have among W identical shards, so a
+    query's rows stop where its initial threshold tau0 = max_t (bound[t] * idf[t]) * qw[t] cuts them (the rest of the top-k
+    would come from the other shards).  Checked against the oracle's full ranked list of the shard, for the first
+    n_check queries: the GPU rows must be a prefix of it (same docs, same score bits, same order) and must hold every oracle
+    row whose score is >= tau0.  Returns (ok, n_checked, message)."""
+    import oracle
+    q_ptr, q_term, q_w = q_host
+    n = int(min(n_check, len(q_ptr) - 1))
+    qs = (q_ptr[: n + 1] - q_ptr[0], q_term[: q_ptr[n]], q_w[: q_ptr[n]])
+    ed, es, ec = oracle.search_batch(host_csr[0], host_csr[1], host_csr[2], host_csr[3], idf_np, qs[0], qs[1], qs[2], k, 1.2, 0.75, avgdl,
+                                     native=True, mode=mode)
+    ed = np.where(ed >= 0, ed + ix.doc_base, -1).astype(np.int32)
+    gd, gs, gc = gpu_rows
+    tb = ix.term_bound.cpu().numpy() if ix.term_bound is not None else None
+    col = 0 if k <= 1 else 1 if k <= 10 else 2 if k <= 100 else 3 if k <= 1000 else -1
+    for q in range(n):
+        t, w = qs[1][qs[0][q]: qs[0][q + 1]], qs[2][qs[0][q]: qs[0][q + 1]]
+        tau0 = np.float32(0.0)
+        if tb is not None and col >= 0 and len(t) and np.all(idf_np[t] >= 0) and np.all(w >= 0):
+            ok_t = (idf_np[t] > 0) & (w > 0)
+            if ok_t.any():
+                tau0 = np.max((tb[t[ok_t], col].astype(np.float32) * idf_np[t[ok_t]]) * w[ok_t].astype(np.float32))  # the kernels' fp32 expression
+        c = int(gc[q])
+        if c > int(ec[q]) or not (np.array_equal(gd[q, :c], ed[q, :c]) and np.array_equal(gs[q, :c].view(np.uint32), es[q, :c].view(np.uint32))):
+            return False, n, f"query {q}: the GPU rows are not a prefix of the oracle's ranked list"
+        need = int(np.sum(es[q, : ec[q]] >= tau0))
+        if c < need:
+            return False, n, f"query {q}: {need} oracle rows score >= tau0 = {tau0}, the GPU returned {c}"
+    return True, n, ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +230,10 @@ def main():
     ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
+    ap.add_argument("--profile-every", type=int, default=1,
+                    help="bracket the kernels of every N-th search with hipEvents (roofline leg); 0 = never (dev: roofline fields are then meaningless)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="batches kept in flight on separate HIP streams in the steady-state leg (0 = 4 for batches of <= 2048 queries, none otherwise)")
     ap.add_argument("--self-launch", action="store_true",
                     help="dev: take the launcher path (child ranks under torch.distributed.run) even at --gpus 1")
     args = ap.parse_args()
@@ -236,12 +272,11 @@ def main():
         args.build_unit_tiles = w.get("unit_tiles", 0)
     n_docs, V, k, nq = w["n_docs"], w["vocab"], w["k"], w["n_queries"]
     want_check = not args.no_cpu_baseline          # oracle checks (and, at N = 1, the timed CPU baseline)
-    if args.emulate_world > 1 and want_check:
-        # the emulated corpus-wide bounds cut this shard's rows below its own top-k (the other shards' docs would fill
-        # them): a timing rehearsal only, nothing to compare with the oracle
-        log("[bench] --emulate-world: timing rehearsal, oracle checks and the CPU baseline are skipped")
-        want_check = False
-    want_cpu = want_check and world == 1 and not args.force_dist
+    # --emulate-world: the emulated corpus-wide bounds cut this shard's rows below its own top-k (the other shards' docs
+    # would fill them), so the rows are checked as what they must be -- a PREFIX of the oracle's ranked list for the shard
+    # that holds every row at or above the query's initial threshold (emulated_bound_check) -- and no CPU baseline is timed
+    emu_check = args.emulate_world > 1 and want_check
+    want_cpu = want_check and world == 1 and not args.force_dist and not emu_check
 
     t_build = time.perf_counter()
     host_csr = None
@@ -322,7 +357,7 @@ def main():
                                             unit_tiles=args.build_unit_tiles, mode="dot" if kind == "splade" else "bm25",
                                             val_dtype="f16" if kind == "splade" else "f32")
         del rows, cols, tf  # (no empty_cache(): 288 GB of HBM, and freeing would idle the GPU before the timed region)
-    ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=True, debug=args.debug,
+    ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=args.profile_every, debug=args.debug,
                 unit_tiles=args.unit_tiles)
     if world > 1 and not args.local_bounds:
         # corpus-wide score bounds (one all-gather of a few MB at start-up): every shard starts from the single-GPU
@@ -422,6 +457,51 @@ def main():
         log(f"[bench] host pipeline: kernels in that loop: wave {pp['wave_ms']:.3f} ms, block {pp['block_ms']:.3f} ms, merge {pp['merge_ms']:.3f} ms per batch")
         pipe.close()
 
+    # ---- steady state with several batches in flight (small batches are launch / latency bound one at a
+    #      time -- C2 moves 48 MB per batch, 6 us at peak -- and the reference's pipeline searches batches of <= 100 queries,
+    #      evaluate_rag_pipeline.py:741,779): `streams` slots, each with its own HIP stream, workspace and result rows,
+    #      (a) device-resident batches, (b) host batches through the multi-stream HostBatchPipeline ----
+    steady = None
+    n_streams = args.streams if args.streams > 0 else (4 if nq <= 2048 else 0)
+    if dist is None and n_streams > 1:
+        ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=False, debug=args.debug, unit_tiles=args.unit_tiles)
+        n_b = max(200, 20 * args.steps)
+        slots = [(torch.cuda.Stream(device=dev), torch.empty(max(ix.workspace_bytes(nq, k), 1 << 16), dtype=torch.uint8, device=dev),
+                  torch.empty((nq, 2 * k + 1), dtype=torch.int32, device=dev)) for _ in range(n_streams)]
+        for rep_ in range(2):  # first pass = warm-up
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for i in range(n_b):
+                st_, ws_, out_ = slots[i % n_streams]
+                ix.search_packed_device(qp, qt, qw, k, out=out_, stream=st_, workspace=ws_)
+            torch.cuda.synchronize(dev)
+            dev_s = (time.perf_counter() - t) / n_b
+        rows = slots[(n_b - 1) % n_streams][2].cpu().numpy()
+        rd, rs, rc_ = (x.cpu().numpy() for x in res)
+        if not args.debug and not (np.array_equal(rows[:, :k], rd) and np.array_equal(rows[:, k:2 * k], rs.view(np.int32)) and np.array_equal(rows[:, 2 * k], rc_)):
+            raise SystemExit("PARITY FAILURE: a multi-stream search returned rows that differ from the single-stream search")
+        pipe = sparse_rx.HostBatchPipeline(ix, nq, len(q_term), k, depth=n_streams, multi_stream=True)
+        for i in range(12):
+            pipe.result(pipe.submit(q_ptr, q_term, q_w))
+        torch.cuda.synchronize(dev)
+        tickets = []
+        t = time.perf_counter()
+        for i in range(n_b):
+            tickets.append(pipe.submit(q_ptr, q_term, q_w))
+            if len(tickets) == n_streams:
+                pd_, ps_, pc_ = pipe.result(tickets.pop(0))
+        while tickets:
+            pd_, ps_, pc_ = pipe.result(tickets.pop(0))
+        host_s = (time.perf_counter() - t) / n_b
+        if not args.debug and not (np.array_equal(pd_, rd) and np.array_equal(ps_.view(np.uint32), rs.view(np.uint32)) and np.array_equal(pc_, rc_)):
+            raise SystemExit("PARITY FAILURE: the multi-stream host pipeline returned rows that differ from the single-stream search")
+        pipe.close()
+        steady = {"streams": n_streams, "batches": n_b, "device_resident_qps": nq / dev_s, "device_resident_ms_per_batch": dev_s * 1e3,
+                  "pcie_inclusive_qps": nq / host_s, "pcie_inclusive_ms_per_batch": host_s * 1e3}
+        log(f"[bench] steady state, {n_streams} batches in flight: {nq / dev_s:,.0f} queries/s device-resident ({dev_s * 1e3:.4f} ms / batch), "
+            f"{nq / host_s:,.0f} queries/s host batches in / host rows out ({host_s * 1e3:.4f} ms / batch); single stream: {1e3 * elapsed / args.steps:.4f} ms / batch")
+        ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=args.profile_every, debug=args.debug, unit_tiles=args.unit_tiles)
+
     # ---- roofline of the dominant kernel (this rank's scoring kernels) --------------------------------------------
     # sum df_t * (doc id bytes + value bytes) + k * 8, with "the smaller actual per-posting size" when the
     # stored layout is smaller than canonical: the tier-1 kernel streams the compact copy (16-bit unit-local doc ids), the
@@ -435,7 +515,7 @@ def main():
     alg_bytes_canonical = n_post * (4 + ix.value_bytes) + nq * k * 8
     # Dominant kernel = the tier-1 wave kernel; the tier-2 block kernel's time is kept in the denominator so that no
     # posting byte is counted without its time.  Per STEP: the per-call averages times the calls one step makes.
-    score_s = (prof["wave_ms"] + prof["block_ms"]) * 1e-3 * calls_per_step
+    score_s = max((prof["wave_ms"] + prof["block_ms"]) * 1e-3 * calls_per_step, 1e-12)
     achieved = alg_bytes / score_s / 1e9
     alg_total = alg_bytes
     if dist is not None:
@@ -480,7 +560,8 @@ def main():
                                f"(pcie_inclusive_qps = host batches in / host rows out)",
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_total, "n_queries": nq, "k": k,
                    "sharding": f"doc-range x{world}" + ((" + RCCL all-to-all of packed per-shard top-k, merge of the own query block, all-gather of merged rows" if args.exchange == "a2a" else " + one RCCL all-gather of packed per-shard top-k") if (world > 1 or args.force_dist) else ""),
-                   "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps, "pcie_inclusive_ms_per_step": pcie_ms},
+                   "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps, "pcie_inclusive_ms_per_step": pcie_ms,
+                   "steady_state": steady},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note, "kernel": dominant,
                      "kernel_ms": prof["wave_ms"] * calls_per_step, "tier2_kernel_ms": prof["block_ms"] * calls_per_step,
@@ -499,8 +580,19 @@ def main():
     if want_check:
         import oracle
         oracle_mode = oracle.MODE_TFIDF_F32 if kind == "splade" else oracle.MODE_BM25_F32
+    # ---- --emulate-world rehearsals: prefix + completeness against the shard's oracle list (emulated_bound_check) ----
+    if emu_check:
+        if rank == 0:
+            gpu_rows = tuple(x.contiguous().cpu().numpy() for x in res)
+            ok, n_chk, msg = emulated_bound_check(ix, host_csr, idf_np, avgdl, (q_ptr, q_term, q_w), k, oracle_mode, gpu_rows)
+            if not ok:
+                log("PARITY FAILURE (emulated corpus-wide bounds): " + msg)
+                raise SystemExit(3)
+            result["parity_check"] = {"queries": n_chk, "shards": 1, "how": f"--emulate-world {args.emulate_world}: GPU rows are a prefix of the "
+                                      "shard's oracle list (bit-exact) and hold every oracle row at or above the query's initial threshold"}
+            result["cpu_baseline"] = None
     # ---- N > 1 (and --force-dist rehearsals): per-shard oracle sample, host merge, compare with the exchanged rows --
-    if want_check and dist is not None:
+    elif want_check and dist is not None:
         gpu_rows = tuple(x.cpu().numpy() for x in res)
         ok, n_chk = sharded_sample_check(dist, rank, world, host_csr, doc_base, idf_np, avgdl, (q_ptr, q_term, q_w), k, oracle_mode, gpu_rows)
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)

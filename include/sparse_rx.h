@@ -61,7 +61,7 @@ typedef enum {
  * Device-resident inverted index of one doc-range shard: term-major postings in BLOCKS + a tile skip table.
  *
  * The postings of a term (ascending shard-local doc id) are cut into one run per UNIT of unit_tiles * G consecutive
- * docs (unit_tiles * G <= 63488 for the tier-1 kernel; srx_auto_unit_tiles picks it).  Every run is padded to a
+ * docs (unit_tiles * G <= 49152 for the tier-1 kernel; srx_auto_unit_tiles picks it).  Every run is padded to a
  * multiple of 4 postings with sentinels (doc -1 - 32 * (term % 64), value 0; trailing sentinel block j holds docs
  * -1 - 32 j) and stored as blocks of 4 postings, docs and values side by side:
  *     SRX_VAL_F32: [d0 d1 d2 d3 | v0 v1 v2 v3]   8 x 32-bit words
@@ -117,7 +117,9 @@ typedef struct {
     int32_t supertile_log2; /* docs per unit = 2^supertile_log2 (>= tile_log2); 0 = the index's unit.  Any unit other than
                              * the one the index was padded for is served by the tier-2 kernel alone (exact, slower) */
     int32_t target_blocks;  /* wave-sized work items to aim for (splits of a query / unsplit rounds + split tail); 0 = auto (3072) */
-    int32_t profile;        /* 1 = bracket each kernel with hipEvents (read with srx_profile_read) */
+    int32_t profile;        /* N > 0: bracket the kernels of every N-th search with hipEvents (read with srx_profile_read); an
+                             * event record between two kernels costs the stream a few microseconds, so sampling keeps the
+                             * timed steps close to unprofiled ones */
     int32_t reserved;       /* debug bits.  Exact results: 8 = every query through the tier-2 (block) kernel, 16 = ignore
                              * term_bound, 128 = no flat-tile path in tier 2, 256 = block merge kernel only, 2048 = no wave-level
                              * dense tiles, 4096 = their masked form even on one-tile units, 8192 = their general selection.  Timing
@@ -217,7 +219,7 @@ int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *
                         int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream);
 
 /* Tiles per unit for a corpus of this density: the largest unit whose average per-term run still fits the tier-1
- * kernel's registers with a 5-sigma margin and whose docs fit the 16-bit local ids of the compact copy (<= 63488).  Host-only,
+ * kernel's registers with a 5-sigma margin and whose docs fit the 16-bit local ids of the compact copy (<= 49152).  Host-only,
  * returns the value. */
 int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, int32_t tile_log2);
 
@@ -236,8 +238,8 @@ int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, 
  * Block b of `post` (n_blocks_total = n_blocks + SRX_BLOCK_PAD of them) becomes
  *     SRX_VAL_F32: [l0 | l1 << 16][l2 | l3 << 16][v0 v1 v2 v3]   6 words
  *     SRX_VAL_F16: [l0 | l1 << 16][l2 | l3 << 16][h0 h1][h2 h3]  4 words
- * with l = doc - first doc of the doc's unit (units of unit_tiles << tile_log2 <= 63488 docs); a sentinel (doc -1 - 32 x)
- * becomes 0xFFFF - 32 (x mod 64).  Derived data: not stored in shard files, rebuilt after a load. */
+ * with l = doc - first doc of the doc's unit (units of unit_tiles << tile_log2 <= 49152 docs); a sentinel (doc -1 - 32 x)
+ * becomes 49152 + 32 (x mod 64).  Derived data: not stored in shard files, rebuilt after a load. */
 int srx_build_compact(int32_t device, int32_t val_type, const int32_t *post, int64_t n_blocks_total, int32_t tile_log2,
                       int32_t unit_tiles, int32_t *out_post16, void *stream);
 

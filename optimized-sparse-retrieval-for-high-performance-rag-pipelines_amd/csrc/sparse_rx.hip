@@ -8,7 +8,7 @@
 //   fast_topk_selection  rag_system/core/retrieval.py:79-92      (+ score>0 filter :292-296)
 //
 // Design: the index is term-major with a tile skip table; a term's postings are stored as blocks of 4
-// (docs and values side by side), one padded run per unit of <= 63488 docs.  A query's doc range is cut into those
+// (docs and values side by side), one padded run per unit of <= 49152 docs.  A query's doc range is cut into those
 // units.  Two tiers score them, a merge kernel ranks:
 //   tier 1  srx_wave_kernel   (wave_kernel.hip) ONE WAVEFRONT per (query, split), no barriers; flags what it cannot
 //           serve (long runs, many multi-term docs, > 64 terms, k > 128) for tier 2.
@@ -1504,7 +1504,7 @@ __global__ void srx_compact_blocks_kernel(const int32_t *__restrict__ post, int6
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int d = src[c];
-        l[c] = d >= 0 ? (unsigned)(d % unit_docs) : 0xFFFFu - 32u * (unsigned)(((-1 - d) >> 5) & 63);
+        l[c] = d >= 0 ? (unsigned)(d % unit_docs) : (unsigned)W_SENT_BASE + 32u * (unsigned)(((-1 - d) >> 5) & 63);
     }
     dst[0] = (int32_t)(l[0] | (l[1] << 16));
     dst[1] = (int32_t)(l[2] | (l[3] << 16));
@@ -1524,6 +1524,7 @@ struct srx_index {
     hipEvent_t *ev;   // PROF_SLOTS x PROF_EVENTS events, created lazily
     int ev_n;         // profiled calls recorded since the last srx_profile_read (<= PROF_SLOTS, then it wraps)
     int64_t ev_calls;
+    int64_t n_calls;  // searches issued (profile = N samples every N-th of them)
     int *h_hint;      // pinned, device-mapped word: the tier-2 worklist length of a recent search (sizes the next tier-2 grid)
     int *d_hint;      // its device address
 };
@@ -1572,6 +1573,7 @@ SRX_API int srx_index_create(const srx_index_desc *d, srx_index **out) {
     ix->ev = nullptr;
     ix->ev_n = 0;
     ix->ev_calls = 0;
+    ix->n_calls = 0;
     // 64 bytes of pinned host memory, created once with the handle (srx_search itself allocates nothing).  Not fatal when
     // it cannot be had: the tier-2 grid then always has its full size.
     ix->h_hint = nullptr;
@@ -1616,7 +1618,7 @@ struct Plan {
     int tpu, n_super, n_splits, n_whole, ovf_words, lists_per_q;  // tpu = tiles per unit; queries < n_whole are not split
 };
 
-// Supertile (unit) = the doc range one tier-1 unit covers (<= 2^W_UNIT_LOG2 docs, the wave bitmap): the unit the
+// Supertile (unit) = the doc range one tier-1 unit covers (<= W_UNIT_MAX_DOCS docs, the wave bitmap): the unit the
 // index's runs were padded for at build time (srx_auto_unit_tiles), unless the options override it (then only tier 2
 // can serve the queries).
 Plan make_plan(const srx_index *ix, int nq, int k) {
@@ -1708,7 +1710,7 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     v.n_tiles = ix->d.n_tiles;
     const int dbg = ix->opts.reserved | (after_score ? 8 : 0);  // search-after: the tier-2 kernel applies the bound, it takes every query
 
-    const bool prof = ix->opts.profile != 0;
+    const bool prof = ix->opts.profile > 0 && (ix->n_calls++ % ix->opts.profile) == 0;  // profile = N: every N-th call is bracketed
     hipEvent_t *ev = nullptr;
     if (prof) {
         if (!ix->ev) {
@@ -1963,7 +1965,7 @@ SRX_API int32_t srx_auto_unit_tiles(int64_t n_docs, int64_t vocab, int64_t nnz, 
         return fail(SRX_ERR_INVALID, "srx_auto_unit_tiles: bad argument%s");
     // The largest unit (in tiles) for which the run of an average term inside a unit overflows the registers of its lane
     // group (8 lanes x W_R postings in the reference case of an 8-term query) with negligible probability (mean +
-    // 5 sigma, Poisson), and whose docs fit the tier-1 bitmap / the compact copy's local ids (63488).
+    // 5 sigma, Poisson), and whose docs fit the tier-1 bitmap / the compact copy's local ids (49152).
     const int max_tpu_bitmap = W_UNIT_MAX_DOCS >> tile_log2;  // 16-bit unit-local ids below the sentinels' range (>= 3 tiles of 16384)
     const double per_doc_per_term = (double)nnz / ((double)n_docs * (double)vocab);
     auto fits = [&](int t) {
@@ -1980,7 +1982,7 @@ SRX_API int srx_build_compact(int32_t device, int32_t val_type, const int32_t *p
     if (!post || !out_post16 || n_blocks_total <= 0) return fail(SRX_ERR_INVALID, "srx_build_compact: bad argument%s");
     if (val_type != SRX_VAL_F32 && val_type != SRX_VAL_F16) return fail(SRX_ERR_INVALID, "srx_build_compact: bad val_type%s");
     if (tile_log2 < 6 || tile_log2 > SRX_MAX_TILE_LOG2 || unit_tiles < 1 || ((int64_t)unit_tiles << tile_log2) > W_UNIT_MAX_DOCS)
-        return fail(SRX_ERR_INVALID, "srx_build_compact: a unit must cover at most 63488 docs (16-bit unit-local ids below the sentinels)%s");
+        return fail(SRX_ERR_INVALID, "srx_build_compact: a unit must cover at most 49152 docs (the tier-1 bitmap; the sentinels' local ids lie above)%s");
     HIP_TRY(hipSetDevice(device));
     hipStream_t stream = (hipStream_t)stream_v;
     const unsigned grid = (unsigned)((n_blocks_total + 255) / 256);

@@ -59,26 +59,31 @@ constexpr int MAX_TPS = 64;                 // tiles per supertile handled by th
 constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thread (4096 per workgroup)
 constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
-constexpr int W_UNIT_LOG2 = 16;             // the wave-private LDS bitmap has 65536 bits: 1 per unit-local doc id
-constexpr int W_UNIT_MAX_DOCS = 65536 - 2048;  // a unit covers <= 63488 docs: the compact tier-1 copy (16-bit unit-local doc ids) leaves the top 2048
-                                            // local ids to the sentinels (0xFFFF - 32 j, j < 64: bitmap words of their own)
-constexpr int W_BM_WORDS = 1 << (W_UNIT_LOG2 - 5);  // 2048 words = 8 KiB
+#ifndef SRX_W_WPE
+#define SRX_W_WPE 5
+#endif
+constexpr int W_WAVES_PER_EU = SRX_W_WPE;   // tier-1 waves per SIMD the kernel is built for: 5 needs <= 96 VGPRs and <= 8 KB of LDS per wave
+                                            // (20 waves per CU x 7.75 KB of the CU's 160 KB), 4 allows 128 VGPRs and 10 KB
+constexpr int W_UNIT_MAX_DOCS = 49152;      // a unit covers <= 49152 docs (3 tiles of 16384): its local doc ids are the bit positions of
+                                            // the wave-private LDS bitmap ...
+constexpr int W_SENT_BASE = 49152;          // ... and the sentinels of the compact copy take the 64 bitmap words above them: local id
+                                            // W_SENT_BASE + 32 j, j < 64 (a word of their own each)
+constexpr int W_BM_WORDS = (W_SENT_BASE + 64 * 32) / 32;  // 1600 words = 6.25 KiB
+constexpr unsigned W_BM_ADR_MASK = 0x1FFCu; // byte offset of a bitmap word from a 16-bit id >> 3 (ids stay below 51200 by construction)
 #ifndef SRX_W_R
 #define SRX_W_R 12
 #endif
-constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8, 12 or 16).  12: 128 VGPRs = 4 waves
-                                            // per SIMD with the 10 KB of LDS per wave (16 measured 2 % slower at 3 waves per SIMD)
-constexpr int W_WAVES_PER_EU = W_R <= 12 ? 4 : 3;  // what the register budget of that choice allows
-constexpr int W_CAP = W_R * 64;             // hence <= 1024 postings per tier-1 unit
+constexpr int W_R = SRX_W_R;                // postings per lane per unit held in registers (8 or 12)
+constexpr int W_CAP = W_R * 64;             // hence <= 768 postings per tier-1 unit
 constexpr int W_DUPCAP = 48;                // dup postings per unit resolved in tier 1 (more: the unit is dense -> tier 2)
-constexpr int W_LCAP = 384;                 // lazy top-k list capacity (entries; a multiple of 64)
+constexpr int W_LCAP = 384;                 // lazy top-k list capacity of the merge wave kernel's callers (entries; a multiple of 64)
 constexpr int W_KMAX = 128;                 // largest k ranked by one wavefront (wave_rank_emit: 2 keys per lane)
 #ifndef SRX_W_LCAP
-#define SRX_W_LCAP 256
+#define SRX_W_LCAP (SRX_W_WPE >= 5 ? 192 : 256)
 #endif
 constexpr int W1_LCAP = SRX_W_LCAP;         // tier 1's lazy top-k list capacity (entries; a multiple of 64)
-constexpr int W1_KMAX = W1_LCAP - 64 - W_DUPCAP - 32 < W_KMAX ? W1_LCAP - 64 - W_DUPCAP - 32 : W_KMAX;  // largest k tier 1 serves: the list
-                                            // keeps room for a unit's multi-term docs, 64 appends and >= 32 entries between selections
+constexpr int W1_KMAX = W1_LCAP - W_DUPCAP - 32 < 112 ? W1_LCAP - W_DUPCAP - 32 : 112;  // largest k tier 1 serves: next to k entries the
+                                            // list keeps room for a unit's multi-term docs and >= 32 single-term candidates
 constexpr int W_MAXT = 64;                  // query terms (each owns 64 / 2^ceil(log2 nt) lanes)
 
 inline int fail(int code, const char *fmt, const char *detail = "") {
@@ -98,7 +103,7 @@ __host__ __device__ inline int bound_column(int k) { return k <= 1 ? 0 : k <= 10
 }  // namespace
 
 // Posting storage (layout v2, "blocked"): the postings of a term are cut into runs, one per UNIT of
-// unit_tiles * 2^tile_log2 <= 63488 consecutive docs; every run is padded to a multiple of 4 postings with sentinels
+// unit_tiles * 2^tile_log2 <= 49152 consecutive docs; every run is padded to a multiple of 4 postings with sentinels
 // (negative doc, value 0) and stored as blocks of 4 postings, docs and values of a block side by side:
 //     f32 values: [d0 d1 d2 d3 | v0 v1 v2 v3]           8 words = 32 bytes
 //     f16 values: [d0 d1 d2 d3 | h0 h1 | h2 h3]          6 words = 24 bytes
@@ -120,7 +125,7 @@ struct BlockWords<__half> {
 //     f32 values: [l0 | l1 << 16][l2 | l3 << 16][v0 v1 v2 v3]   6 words = 24 bytes  (8 -> 6 bytes per posting)
 //     f16 values: [l0 | l1 << 16][l2 | l3 << 16][h0 h1][h2 h3]  4 words = 16 bytes  (6 -> 4 bytes per posting)
 // local id = doc - unit_first_doc (units of unit_tiles << tile_log2 <= W_UNIT_MAX_DOCS docs); a sentinel (doc -1 - 32 x)
-// becomes 0xFFFF - 32 (x mod 64): above every real local id, a bitmap word of its own, value 0 as before.
+// becomes W_SENT_BASE + 32 (x mod 64): above every real local id, a bitmap word of its own, value 0 as before.
 template <typename VT>
 struct CompactWords {
     static constexpr int value = 6;

@@ -4,9 +4,9 @@
 // (rag_system/pipeline/evaluate_rag_pipeline.py:95-121) for queries of <= 64 terms at k <= 112 (W1_KMAX).
 //
 // Layout it relies on (srx_common.h, IndexView): a term's postings are padded runs of blocks [4 docs | 4 values], one run
-// per unit of <= 63488 docs; tier 1 streams the COMPACT copy of the blocks (post16: 16-bit unit-local doc ids, 24 bytes per
+// per unit of <= 49152 docs; tier 1 streams the COMPACT copy of the blocks (post16: 16-bit unit-local doc ids, 24 bytes per
 // block with fp32 values, 16 with fp16 -- 6 / 4 bytes per posting instead of 8 / 6: the kernel runs at the HBM ceiling, so
-// bytes are time); padding postings are sentinels (local id 0xFFFF - 32 x, above every real local id, value 0) and idle
+// bytes are time); padding postings are sentinels (local id 49152 + 32 x, above every real local id, value 0) and idle
 // loads are redirected to an all-sentinel block of the lane's own (their bitmap words differ per lane / per term: LDS
 // atomics of several lanes on one address serialise).  A posting with value 0 is a no-op by construction of every step
 // below, so the unit loop needs NO per-posting validity predicate:
@@ -42,16 +42,10 @@ namespace {
 
 enum { U_OK = 0, U_DENSE = 1, U_FULL = 2 };  // outcome of scoring one unit (see process)
 
-#ifndef SRX_W_WPE
-#define SRX_W_WPE W_WAVES_PER_EU
-#endif
-#ifndef SRX_W_CLEAR_BY_ADDRESS_UPTO
-#define SRX_W_CLEAR_BY_ADDRESS_UPTO 4  // units of up to this many slots per lane clear their bitmap words one by one (addresses recomputed from the ids), larger ones clear the whole bitmap with 8 wide stores
-#endif
 #ifndef SRX_W_DEPTH
 #define SRX_W_DEPTH 2  // register sets: units in flight + the one being scored
 #endif
-struct WaveShared2 {
+struct WaveShared2 {  // 6400 + 8 LCAP bytes: 7936 at 5 waves per SIMD (20 x 7936 <= 160 KB), 8448 at 4
     static constexpr int LCAP = W1_LCAP;
     static constexpr bool HIST_ALIASES_ZEROED_LDS = true;
     union {
@@ -62,6 +56,7 @@ struct WaveShared2 {
     unsigned lbits[LCAP];         // lazy top-k list (score bits, doc), unordered
     int ldoc[LCAP];
 };
+static_assert(sizeof(WaveShared2) * 4 * W_WAVES_PER_EU <= 160 * 1024, "tier-1 LDS per wave does not allow the waves per SIMD the kernel is built for");
 
 // The unit-local doc ids stay PACKED in registers the way the compact copy stores them (two 16-bit ids per word: slot r
 // lives in half r & 1 of word r >> 1): a register set is W_R / 2 + W_R VGPRs instead of 2 W_R, which is what pays for the
@@ -171,7 +166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         }
         unsigned tau_seen = 0xFFFFFFFFu;  // uniform: tau the screening threshold vthr was derived from
         float vthr = 0.0f;
-        const int32_t *const zblk = ix.post16 + (ix.zero_block + lane) * BW;  // my lane's all-sentinel block (local id 0xFFFF - 32 lane)
+        const int32_t *const zblk = ix.post16 + (ix.zero_block + lane) * BW;  // my lane's all-sentinel block (local id W_SENT_BASE + 32 lane)
         const int32_t *const tpost = ix.post16 + (tblk + jl) * BW;       // my lane's first block of the term
 
         // unit boundary j of my term in padded POSTINGS from the term's start (#padded postings with doc < j * tpu * G; a
@@ -214,50 +209,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             constexpr int NR = decltype(nrc)::value;
             const unsigned count0 = tk.count;
             if (count0 + (unsigned)W_DUPCAP + 1u > (unsigned)WaveShared2::LCAP) return U_FULL;  // uniform, rare: room for this unit's multi-term docs
-            // ---- pass 1: doc bits.  Every slot ORs its bit into the bitmap word of its id; the word that comes back tells
-            //      whether an earlier posting (another term's) matched the same doc: fm = the lane's slots that found their bit
-            //      already set.  Nothing but the returned words is kept across the LDS round trip (the bit position is read
-            //      again from the id register with v_bfe), and nothing is kept for the clean-up below ----
-            unsigned old[NR];
+            // ---- pass 1: doc bits.  Every slot ORs its bit into the bitmap word of its id; `old & bit` != 0 means an earlier
+            //      posting (another term's) matched the same doc.  5 VALU + 1 LDS instruction per slot: the byte address and
+            //      the bit stay in registers across the LDS round trip (the loop has them to spare now that the list
+            //      selection left it) -- recomputing them afterwards cost ~3.5 VALU per slot and 4 % of the batch ----
+            unsigned adr[NR], t[NR];  // t[r] != 0: slot r found its doc's bit already set
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const unsigned w = d[r >> 1];  // id = half r & 1 of the word
-                const unsigned adr = (w >> ((r & 1) ? 19 : 3)) & (unsigned)((W_BM_WORDS - 1) << 2);  // byte offset of word (id >> 5) & 2047
+                adr[r] = (w >> ((r & 1) ? 19 : 3)) & W_BM_ADR_MASK;  // byte offset of word id >> 5
                 unsigned one;  // min(value bits, 1): 0 for a value of exactly +0 (v_min_u32; the compiler's own form is cmp + cndmask)
                 asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(__float_as_uint(v[r])));
                 const unsigned bit = one << (((r & 1) ? w >> 16 : w) & 31u);
-                old[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr), bit);
+                t[r] = atomicOr(reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]), bit) & bit;
             }
-            unsigned fm = 0;
+            unsigned acc = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {  // a sentinel's word is all zero (a word of its own per lane, value 0 sets no bit)
-                const unsigned w = d[r >> 1];
-                fm |= __builtin_amdgcn_ubfe(old[r], ((r & 1) ? w >> 16 : w) & 31u, 1u) << r;
-            }
+            for (int r = 0; r < NR; ++r) acc |= t[r];
             bool dense = false;
-            const bool anydup = __ballot(fm != 0u) != 0ull;
+            const bool anydup = __ballot(acc != 0u) != 0ull;
             STAMP(2);  // wait for the unit's postings + pass 1
             CNT(0);
-            // ---- the bitmap goes back to all zero: 8 wide stores (no address is kept per slot; a unit with one load step
-            //      clears its four words by address) ----
-            if constexpr (NR <= SRX_W_CLEAR_BY_ADDRESS_UPTO) {
+            // ---- the bitmap words go back to zero (measured: clearing the whole 8 KB bitmap with 8 wide stores per lane
+            //      instead, which needs no addresses, costs the batch 14 % -- LDS write bandwidth) ----
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const unsigned w = d[r >> 1];
-                    *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + ((w >> ((r & 1) ? 19 : 3)) & (unsigned)((W_BM_WORDS - 1) << 2))) = 0u;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < W_BM_WORDS / 256; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-            }
+            for (int r = 0; r < NR; ++r) *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(S.bm) + adr[r]) = 0u;
             STAMP(4);  // restore
             if (anydup && !(dbg & 1)) {  // uniform: some doc of this unit is matched by several terms (~3 units in 4 on C3)
                 CNT(1);
                 // Lanes with a flagged posting (typically one or two) are visited one after the other: fm = the lane's
                 // flagged slots; the doc of its lowest flagged slot is broadcast, every lane picks up and blanks its
                 // posting of that doc (a doc occurs at most once per term, hence at most once per lane; sentinels carry
-                // local ids no real posting has; a posting whose stored value is exactly 0 may be flagged too: it adds
-                // nothing), and the contributions are added in ascending lane order = the query's term order.
+                // local ids no real posting has), and the contributions are added in ascending lane order = the query's term order.
+                unsigned fm = 0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    unsigned one;
+                    asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(t[r]));
+                    fm |= one << r;
+                }
                 unsigned n_res = 0;
                 unsigned long long m = __ballot(fm != 0u);
                 while (m != 0ull) {  // uniform loop: about two docs per such unit on C3

@@ -201,7 +201,7 @@ class DeviceIndex:
     def value_bytes(self) -> int:
         return 4 if self.val_type == _capi.SRX_VAL_F32 else 2
 
-    UNIT_MAX_DOCS = 65536 - 2048  # W_UNIT_MAX_DOCS in csrc/srx_common.h
+    UNIT_MAX_DOCS = 49152  # W_UNIT_MAX_DOCS in csrc/srx_common.h
 
     def _build_compact(self):
         """The compact copy of the blocks the tier-1 kernel streams (16-bit unit-local doc ids: 6 / 4 bytes per posting
@@ -447,8 +447,9 @@ class DeviceIndex:
                        val_type=int(meta["val_type"]), term_bound=tb, fine_bound=fb)
 
     # -- search ----------------------------------------------------------------------------------------
-    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: bool = False, debug: int = 0,
+    def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: int = 0, debug: int = 0,
                  unit_tiles: int = 0) -> None:
+        """profile = N > 0: every N-th search is bracketed with hipEvents (True = every search)."""
         self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile),
                                       reserved=int(debug), unit_tiles=int(unit_tiles))
         _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
@@ -543,7 +544,9 @@ class DeviceIndex:
     def profile_read(self):
         """Average kernel durations (ms) over the profiled searches since the last read."""
         ms = (ctypes.c_float * 4)()
-        n = _capi.check(_capi.lib().srx_profile_read(self._h, ms), "srx_profile_read")
+        n = _capi.lib().srx_profile_read(self._h, ms)
+        if n < 0:  # nothing was profiled since the last read
+            return {"wave_ms": 0.0, "block_ms": 0.0, "merge_ms": 0.0, "total_ms": 0.0, "calls": 0}
         return {"wave_ms": ms[0], "block_ms": ms[1], "merge_ms": ms[2], "total_ms": ms[3], "calls": n}
 
     def device_bytes(self) -> int:
@@ -582,7 +585,7 @@ class HostBatchPipeline:
     block, no D2H copy call either; ``False`` keeps the device block + one ``hipMemcpyAsync`` on the copy stream."""
 
     def __init__(self, index: "DeviceIndex", max_queries: int, max_terms: int, k: int, depth: int = 3, validate: bool = True,
-                 zero_copy_queries: bool = True, zero_copy_results: bool = True):
+                 zero_copy_queries: bool = True, zero_copy_results: bool = True, multi_stream: bool = False):
         torch = _torch()
         if not (1 <= k <= _capi.limits()["max_k"]):
             raise ValueError(f"top_k must be in [1, {_capi.limits()['max_k']}] for the HIP engine, got {k}")
@@ -590,6 +593,10 @@ class HostBatchPipeline:
         self.zero_copy = bool(zero_copy_queries)
         self.zero_copy_out = bool(zero_copy_results)
         self.max_queries, self.max_terms = int(max_queries), int(max_terms)
+        # multi_stream: every slot searches on a HIP stream of its own with a workspace of its own, so that `depth` batches
+        # are in flight on the GPU at once -- what small batches need (a 1 k-query batch fills a fraction of the chip for
+        # ~0.05 ms: back to back on one stream the launches, not the kernels, set the rate).  Large batches gain nothing.
+        self.multi_stream = bool(multi_stream)
         dev = index.device
         qwords = self.max_queries + 1 + 2 * self.max_terms
         row = 2 * self.k + 1
@@ -603,6 +610,9 @@ class HostBatchPipeline:
                     "h_out": torch.empty((self.max_queries, row), dtype=torch.int32).pin_memory(),
                     "ev_done": torch.cuda.Event(), "ev_out": torch.cuda.Event(), "busy": False, "nq": 0})
                 self.slots[-1]["h_q_np"] = self.slots[-1]["h_q"].numpy()
+                if self.multi_stream:
+                    self.slots[-1]["stream"] = torch.cuda.Stream(device=dev)
+                    self.slots[-1]["ws"] = torch.empty(max(index.workspace_bytes(self.max_queries, self.k), 1 << 16), dtype=torch.uint8, device=dev)
             torch.cuda.synchronize(dev)
         self._n = 0
         self.host_times = [0.0, 0.0, 0.0, 0.0]  # submit(): validate, staging, search call, events + D2H call (seconds, cumulative)
@@ -629,16 +639,22 @@ class HostBatchPipeline:
         hq[nq + 1 + nt: nq + 1 + 2 * nt].view(np.float32)[:] = q_weight[:nt]
         n_words = nq + 1 + 2 * nt
         t2 = _time.perf_counter()
-        main = torch.cuda.current_stream(self.index.device)
+        main = s["stream"] if self.multi_stream else torch.cuda.current_stream(self.index.device)
         if self.zero_copy:
             dq = s["h_q"]  # pinned host memory is mapped into the device's address space: the kernels read it in place
         else:
             _capi.check(L.srx_memcpy_async(s["d_q"].data_ptr(), s["h_q"].data_ptr(), 4 * n_words, main.cuda_stream), "srx_memcpy_async")
             dq = s["d_q"]
         out = s["h_out"] if self.zero_copy_out else s["d_out"]
+        if nq and self.multi_stream:
+            need = self.index.workspace_bytes(nq, self.k)  # not monotone in nq (fewer queries are cut into more splits)
+            if s["ws"].numel() < need:
+                s["stream"].synchronize()
+                s["ws"] = torch.empty(need, dtype=torch.uint8, device=self.index.device)
         if nq:
             self.index.search_packed_device(dq[: nq + 1], dq[nq + 1: nq + 1 + nt], dq[nq + 1 + nt: n_words].view(torch.float32),
-                                            self.k, out=out[:nq])
+                                            self.k, out=out[:nq], stream=main if self.multi_stream else None,
+                                            workspace=s["ws"] if self.multi_stream else None)
         t3 = _time.perf_counter()
         if self.zero_copy_out:
             # the kernels wrote the rows straight into the pinned (device-mapped) host block: posted writes over PCIe while

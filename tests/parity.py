@@ -99,12 +99,12 @@ def np_build_blocks(indptr, indices, data, n_docs, vocab, tile_log2, unit_tiles,
 
 def np_compact_blocks(post, unit_docs, val_dtype=np.float32):
     """NumPy restatement of the compact copy the tier-1 kernel streams (include/sparse_rx.h, srx_build_compact): per block
-    four 16-bit unit-local doc ids (doc mod unit_docs; a sentinel -1 - 32 x becomes 0xFFFF - 32 (x mod 64)) packed in two
+    four 16-bit unit-local doc ids (doc mod unit_docs; a sentinel -1 - 32 x becomes 49152 + 32 (x mod 64)) packed in two
     words, then the value words unchanged."""
     words = 8 if val_dtype == np.float32 else 6
     b = np.asarray(post, np.int32).reshape(-1, words)
     d = b[:, :4].astype(np.int64)
-    loc = np.where(d >= 0, d % unit_docs, 0xFFFF - 32 * (((-1 - d) >> 5) & 63)).astype(np.uint32)
+    loc = np.where(d >= 0, d % unit_docs, 49152 + 32 * (((-1 - d) >> 5) & 63)).astype(np.uint32)
     out = np.zeros((b.shape[0], words - 2), np.int32)
     out[:, 0] = (loc[:, 0] | (loc[:, 1] << 16)).astype(np.uint32).view(np.int32)
     out[:, 1] = (loc[:, 2] | (loc[:, 3] << 16)).astype(np.uint32).view(np.int32)

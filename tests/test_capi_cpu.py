@@ -34,7 +34,7 @@ def test_limits_and_error_strings():
         _capi.check(L.srx_merge_workspace_bytes(1, 0, 10), "srx_merge_workspace_bytes")
     # argument checks of the round-2 entry points (all return before anything touches a device)
     assert L.srx_build_compact(0, 0, None, 10, 14, 3, None, None) == -1 and b"srx_build_compact" in L.srx_last_error()
-    assert L.srx_build_compact(0, 0, 1 << 20, 10, 14, 4, 1 << 21, None) == -1 and b"63488" in L.srx_last_error()   # 4 x 16384 docs per unit
+    assert L.srx_build_compact(0, 0, 1 << 20, 10, 14, 4, 1 << 21, None) == -1 and b"49152" in L.srx_last_error()   # 4 x 16384 docs per unit
     assert L.srx_build_compact(0, 7, 1 << 20, 10, 14, 3, 1 << 21, None) == -1 and b"val_type" in L.srx_last_error()
     assert L.srx_dense_search_u8(0, 1 << 20, None, 10, 64, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1
     assert L.srx_dense_search_u8(0, 1 << 20, 1 << 26, 10, 48, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1

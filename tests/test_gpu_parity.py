@@ -398,9 +398,9 @@ def test_blocked_layout_matches_numpy_builder(rx):
             assert np.array_equal(ix.post16.cpu().numpy(), np_compact_blocks(post, ut << 8, npd)), (ut, vd)
             ix.close()
     auto = rx.DeviceIndex.from_csr(c.indptr, c.indices, c.data, idf, mode="dot", tile_log2=8)
-    assert 1 <= auto.unit_tiles <= 64 and (auto.unit_tiles << 8) <= 65536 - 2048
+    assert 1 <= auto.unit_tiles <= 64 and (auto.unit_tiles << 8) <= 49152
     auto.close()
-    # a unit of more than 63488 docs has no compact copy: tier 2 serves every query, results stay exact
+    # a unit of more than 49152 docs has no compact copy: tier 2 serves every query, results stay exact
     big = synth.uniform_corpus_np(70_000, 500, 6, seed=5)
     ixb = rx.DeviceIndex.from_csr(big.indptr, big.indices, big.data, np.ones(big.vocab, np.float32), mode="dot", tile_log2=14, unit_tiles=4)
     assert ixb.post16 is None
@@ -495,6 +495,103 @@ def test_c3_full_size_properties(rx):
     ix.set_opts(debug=8)                                         # the same sub-batch through the tier-2 kernel alone
     dt, st, nt_ = ix.search(*qs, k)
     assert np.array_equal(dt, ds) and np.array_equal(st.view(np.uint32), ss.view(np.uint32)) and np.array_equal(nt_, ns)
+    ix.close()
+
+
+def _full_size_index(rx, kind, n_docs, V, nnz_per_doc, seed, want_host_csr, **build_kw):
+    """A BASELINE-size corpus generated on the device chunk by chunk (the generators of bench.py), its DeviceIndex, and
+    -- for the oracle sample -- the doc-major CSR on the host."""
+    import torch
+    from sparse_rx import synth
+    dev = torch.device("cuda:0")
+    gen = {"uniform": synth.uniform_chunk_torch, "zipf": synth.zipf_chunk_torch, "splade": synth.splade_chunk_torch}[kind]
+    rows_l, cols_l, tf_l, dl_l = [], [], [], []
+    for ci in range(n_docs // synth.CHUNK_DOCS):
+        r, cc, tf, dl = gen(ci, synth.CHUNK_DOCS, V, nnz_per_doc, seed, dev)
+        rows_l.append(r + ci * synth.CHUNK_DOCS); cols_l.append(cc); tf_l.append(tf); dl_l.append(dl)
+    rows, cols, tf, dl = torch.cat(rows_l), torch.cat(cols_l), torch.cat(tf_l), torch.cat(dl_l)
+    del rows_l, cols_l, tf_l, dl_l
+    if kind == "splade":
+        idf_np, avgdl = np.ones(V, dtype=np.float32), 1.0
+    else:
+        df = torch.bincount(cols, minlength=V).cpu().numpy()
+        idf_np = np.log((n_docs - df + 0.5) / (df + 0.5)).astype(np.float32)
+        avgdl = float(np.mean(dl.cpu().numpy()))
+    host = None
+    if want_host_csr:
+        indptr = torch.zeros(n_docs + 1, dtype=torch.int64, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n_docs), 0)
+        host = (indptr.cpu().numpy(), cols.cpu().numpy(), tf.cpu().numpy(), dl.cpu().numpy())
+        del indptr
+    ix = rx.DeviceIndex.from_coo(rows, cols, tf, torch.as_tensor(idf_np, device=dev), n_docs, doc_lengths=dl, avgdl=avgdl, device=dev,
+                                 mode="dot" if kind == "splade" else "bm25", val_dtype="f16" if kind == "splade" else "f32", **build_kw)
+    del rows, cols, tf
+    return ix, idf_np, avgdl, host
+
+
+def _assert_rows_equal(a, b, label):
+    assert np.array_equal(a[2], b[2]), f"{label}: counts"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), f"{label}: rows"
+
+
+def _sub_batch(q, lo, hi):
+    return ((q[0][lo: hi + 1] - q[0][lo]).astype(np.int32), q[1][q[0][lo]: q[0][hi]], q[2][q[0][lo]: q[0][hi]])
+
+
+def test_c4_full_size(rx):
+    """BASELINE config C4 at FULL size: SPLADE-style learned sparse, 5 M docs x 30 k vocab, ~150 nnz / doc, fp16 weights, 1 000
+    queries x 50 terms, k = 1000 (bench.py --workload c4: 4096-doc tiles, one-tile units -> the tier-2 kernel's wave-level
+    dense tiles).  A 16-query sample against the oracle's full scan, and size-independent properties over the whole batch:
+    canonical order, idempotence, the k-prefix property ACROSS tiers (k = 100 is ranked by tier 1 from the compact copy,
+    k = 1000 by tier 2 from the canonical blocks), a sub-batch under another work-item plan, the block-level dense tiles."""
+    from sparse_rx import synth
+    n_docs, V, nq, k = 5_000_000, 30_000, 1_000, 1000
+    ix, idf, avgdl, host = _full_size_index(rx, "splade", n_docs, V, 150, 20254, True, tile_log2=12, unit_tiles=1)
+    q = synth.queries_np(nq, V, 50, seed=20255, dist="zipf", s=0.7, weights="learned")
+    got = ix.search(*q, k)
+    d, s, n = got
+    assert np.all(n == k) and np.all(d >= 0) and np.all(d < n_docs) and np.all(s > 0)
+    assert np.all((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (d[:, :-1] < d[:, 1:])))
+    qs16 = _sub_batch(q, 0, 16)
+    exp = oracle.search_batch(host[0], host[1], host[2], host[3], idf, qs16[0], qs16[1], qs16[2], k, 1.2, 0.75, avgdl, native=True,
+                              mode=oracle.MODE_TFIDF_F32)
+    _assert_exact((d[:16], s[:16], n[:16]), exp, "c4 oracle sample")
+    del host
+    _assert_rows_equal(ix.search(*q, k), got, "c4 idempotence")
+    d100, s100, n100 = ix.search(*q, 100)   # tier 1 (k <= 112): other kernel, other copy of the postings
+    _assert_rows_equal((d100, s100, n100), (d[:, :100], s[:, :100], np.minimum(n, 100)), "c4 k-prefix across tiers")
+    sub = _sub_batch(q, 400, 464)
+    _assert_rows_equal(ix.search(*sub, k), (d[400:464], s[400:464], n[400:464]), "c4 sub-batch")
+    ix.set_opts(debug=2048)  # block-level dense tiles instead of the wave-level ones
+    _assert_rows_equal(ix.search(*sub, k), (d[400:464], s[400:464], n[400:464]), "c4 block-level dense tiles")
+    ix.close()
+
+
+def test_c5_full_size(rx):
+    """BASELINE config C5 at FULL size: Zipf(1.0) postings, 10 M docs x 100 k vocab, 256 queries of hot terms (negative idf
+    among them), k = 100 -- long posting runs, tier 2's dense tiles.  A 16-query oracle sample + canonical order,
+    idempotence, k-prefix, a sub-batch under another plan, and the tier-2 kernel alone against the default two-tier plan."""
+    from sparse_rx import synth
+    n_docs, V, nq, k = 10_000_000, 100_000, 256, 100
+    ix, idf, avgdl, host = _full_size_index(rx, "zipf", n_docs, V, 100, 20255, True, tile_log2=14)
+    q = synth.queries_np(nq, V, 8, seed=20256, dist="zipf", s=1.0)
+    got = ix.search(*q, k)
+    d, s, n = got
+    full = n == k
+    assert full.mean() > 0.5 and np.all(d[full] >= 0) and np.all(d < n_docs)
+    rows_ok = (s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & ((d[:, :-1] < d[:, 1:]) | (d[:, 1:] < 0)))
+    assert np.all(rows_ok)
+    qs16 = _sub_batch(q, 0, 16)
+    exp = oracle.search_batch(host[0], host[1], host[2], host[3], idf, qs16[0], qs16[1], qs16[2], k, 1.2, 0.75, avgdl, native=True)
+    _assert_exact((d[:16], s[:16], n[:16]), exp, "c5 oracle sample")
+    del host
+    _assert_rows_equal(ix.search(*q, k), got, "c5 idempotence")
+    d10, s10, n10 = ix.search(*q, 10)
+    _assert_rows_equal((d10, s10, n10), (d[:, :10], s[:, :10], np.minimum(n, 10)), "c5 k-prefix")
+    sub = _sub_batch(q, 100, 132)
+    _assert_rows_equal(ix.search(*sub, k), (d[100:132], s[100:132], n[100:132]), "c5 sub-batch")
+    ix.set_opts(debug=8)  # everything through the tier-2 kernel
+    _assert_rows_equal(ix.search(*q, k), got, "c5 tier 2 alone")
     ix.close()
 
 
