@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--pipe-depth", type=int, default=3, help="host-batch pipeline slots (PCIe-inclusive leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL exchange + packed merge + sharded self-check) with world size 1")
-    ap.add_argument("--profile-every", type=int, default=1,
+    ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket the kernels of every N-th search with hipEvents (roofline leg); 0 = never (dev: roofline fields are then meaningless)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batches kept in flight on separate HIP streams in the steady-state leg (0 = 4 for batches of <= 2048 queries, none otherwise)")
@@ -254,6 +254,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # Everything below is submitted from a stream of our own, not from the legacy default stream: the default stream
+    # synchronises implicitly with blocking streams (RCCL's among them), which serialised the scoring of a batch behind the
+    # exchange of the one before it (profiles/r03_exchange_timeline_default_stream.txt)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     import sparse_rx
     from sparse_rx import synth

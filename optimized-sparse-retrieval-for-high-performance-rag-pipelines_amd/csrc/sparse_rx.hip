@@ -944,7 +944,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
     const int su_hi = (int)(((int64_t)n_super * (split + 1)) / nsq);
     // Tier 2 takes the whole query when tier 1 cannot serve it, otherwise only the units tier 1 flagged.
     const bool all_units = tier1_cannot_serve(ix, nt_all, k, tpu, dbg);
-    const unsigned *my_ovf = ovf + (int64_t)q * ovf_words;
+    const unsigned *my_ovf = ovf + (int64_t)bid * ovf_words;  // the flags tier 1's item of the same (query, split) left
     bool any = all_units && nt_all > 0;
     if (!all_units && nt_all > 0)
         for (int wd = su_lo >> 5; wd <= (su_hi - 1) >> 5 && su_lo < su_hi; ++wd) any = any || (my_ovf[wd] != 0u);
@@ -1668,7 +1668,8 @@ SRX_API int64_t srx_search_workspace_bytes(const srx_index *ix, int32_t nq, int3
     if (!ix || nq < 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_search_workspace_bytes: bad argument%s");
     const Plan p = make_plan(ix, nq, k);
     const int64_t lists = (int64_t)nq * p.lists_per_q;
-    return lists * k * 8 + lists * 4 + (int64_t)nq * p.ovf_words * 4 + 4 * (1 + (int64_t)nq * p.n_splits) + 256;
+    const int64_t items = (int64_t)p.n_whole + (int64_t)(nq - p.n_whole) * p.n_splits;
+    return lists * k * 8 + lists * 4 + items * p.ovf_words * 4 + 4 * (1 + (int64_t)(nq - p.n_whole)) + 4 * items + 256;
 }
 
 namespace {
@@ -1692,8 +1693,9 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     int32_t *cand_doc = (int32_t *)workspace;
     float *cand_score = (float *)(cand_doc + lists * k);
     int32_t *cand_count = (int32_t *)(cand_score + lists * k);
-    unsigned *ovf = (unsigned *)(cand_count + lists);
-    int *work = (int *)(ovf + (int64_t)nq * p.ovf_words);  // work[0] = count, then block ids
+    unsigned *ovf = (unsigned *)(cand_count + lists);      // [blocks][ovf_words]
+    unsigned *done = ovf + blocks * p.ovf_words;            // the zeroed region: arrival counters of the split queries [nq - n_whole] ...
+    int *work = (int *)(done + (nq - p.n_whole));           // ... and work[0] = the worklist length; its entries work[1 .. blocks] follow
 
     IndexView v;
     v.term_ptr = ix->d.term_ptr;
@@ -1720,8 +1722,9 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
         }
         ev = ix->ev + PROF_EVENTS * (int)(ix->ev_calls % PROF_SLOTS);
     }
-    // one memset: list counts (tier-2 lists that never run must read as empty), overflow bitmap, worklist counter
-    HIP_TRY(hipMemsetAsync(cand_count, 0, (size_t)(lists + (int64_t)nq * p.ovf_words + 1) * 4, stream));
+    // one small memset: the worklist length and the split queries' arrival counters (a few KB: one fill launch); every other
+    // slot of the workspace is initialised by the tier-1 work item that owns it
+    HIP_TRY(hipMemsetAsync(done, 0, (size_t)(1 + (nq - p.n_whole)) * 4, stream));
     if (prof) HIP_TRY(hipEventRecord(ev[0], stream));
     // tier 1: one wavefront per (query, split) (wave_kernel.hip)
     {
@@ -1730,7 +1733,7 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
         wl.q_ptr = q_ptr; wl.q_term = q_term; wl.q_weight = q_weight;
         wl.nq = nq; wl.k = k; wl.n_splits = p.n_splits; wl.n_whole = p.n_whole; wl.n_super = p.n_super;
         wl.dbg = dbg | (p.tpu != ix->d.unit_tiles ? 8 : 0);  // another unit than the padded one: everything to tier 2
-        wl.ovf = ovf; wl.ovf_words = p.ovf_words; wl.lists_per_q = p.lists_per_q; wl.work = work;
+        wl.ovf = ovf; wl.ovf_words = p.ovf_words; wl.lists_per_q = p.lists_per_q; wl.work = work; wl.done = done;
         wl.cand_doc = cand_doc; wl.cand_score = cand_score; wl.cand_count = cand_count;
         wl.doc_base = ix->d.doc_base; wl.out_doc = out_doc; wl.out_score = out_score; wl.out_count = out_count;
         wl.out_row_stride = ors; wl.out_cnt_stride = ocs;

@@ -19,7 +19,7 @@
 #define SRX_API extern "C" __attribute__((visibility("default")))
 
 #ifdef SRX_STAMP
-__device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_stamp[32];
 #define STAMP(i)                                                                         \
     do {                                                                                 \
         unsigned long long t_;                                                           \
@@ -60,10 +60,11 @@ constexpr int MERGE_NPT = 16;               // merge kernel: candidates per thre
 constexpr int EMPTY_KEY = -1;
 // tier 1 (one wavefront per (query, split))
 #ifndef SRX_W_WPE
-#define SRX_W_WPE 5
+#define SRX_W_WPE 4
 #endif
-constexpr int W_WAVES_PER_EU = SRX_W_WPE;   // tier-1 waves per SIMD the kernel is built for: 5 needs <= 96 VGPRs and <= 8 KB of LDS per wave
-                                            // (20 waves per CU x 7.75 KB of the CU's 160 KB), 4 allows 128 VGPRs and 10 KB
+constexpr int W_WAVES_PER_EU = SRX_W_WPE;   // tier-1 waves per SIMD the kernel is compiled for (its register budget).  The kernel needs 94 VGPRs
+                                            // and 8.25 KB of LDS per wave, so 19 waves are resident per CU.  Built for 5 (192-entry list, 7.75 KB:
+                                            // 20 waves per CU) it measured 1 % slower on C3 and 4 % slower on a 1.25 M-doc shard (more selections)
 constexpr int W_UNIT_MAX_DOCS = 49152;      // a unit covers <= 49152 docs (3 tiles of 16384): its local doc ids are the bit positions of
                                             // the wave-private LDS bitmap ...
 constexpr int W_SENT_BASE = 49152;          // ... and the sentinels of the compact copy take the 64 bitmap words above them: local id
@@ -163,6 +164,14 @@ typedef int srx_i2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ int gload_i32(const int32_t *p) { return *(const SRX_GLOBAL int32_t *)p; }
 __device__ __forceinline__ srx_i4u gload_i4(const int32_t *p) { return *(const SRX_GLOBAL srx_i4u *)p; }
 __device__ __forceinline__ srx_i2u gload_i2(const int32_t *p) { return *(const SRX_GLOBAL srx_i2u *)p; }
+
+// Loads through the CONSTANT address space: with a wave-uniform address the compiler emits a scalar load (s_load), which
+// travels through the scalar data cache and not through the CU's vector memory pipeline.  Only for data nothing in the
+// kernel writes (index arrays, the query batch).
+#define SRX_CONSTANT __attribute__((address_space(4)))
+__device__ __forceinline__ int cload_i32(const int32_t *p) { return *(const SRX_CONSTANT int32_t *)p; }
+__device__ __forceinline__ float cload_f32(const float *p) { return *(const SRX_CONSTANT float *)p; }
+__device__ __forceinline__ int64_t cload_i64(const int64_t *p) { return *(const SRX_CONSTANT int64_t *)p; }
 
 // one posting by padded position (scalar access: tier 2's hash / flat paths)
 template <typename VT>
@@ -740,9 +749,10 @@ struct srx_wave_launch {
     const int32_t *q_ptr, *q_term;
     const float *q_weight;
     int nq, k, n_splits, n_whole, n_super, dbg;
-    unsigned *ovf;
+    unsigned *ovf;       // [work items][ovf_words]: units item i left to tier 2 (bit su)
     int ovf_words, lists_per_q;
     int *work;
+    unsigned *done;      // [nq - n_whole], zeroed before the launch: arrivals of a split query's items (see the kernel's tail)
     int32_t *cand_doc;
     float *cand_score;
     int32_t *cand_count;

@@ -97,7 +97,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
     const int64_t list = (int64_t)q * a.lists_per_q + split;
     const int t0 = a.q_ptr[q];
     const int nt = a.q_ptr[q + 1] - t0;
+    const int n_terms_all = a.q_ptr[a.nq];  // length of q_term / q_weight (the scalar prologue reads whole vectors of them)
     const int tpu = ix.unit_tiles;
+    // This item's slots of the workspace are initialised here, not by a memset in front of the kernel (which was two fill
+    // launches, ~10 us of a 0.2 ms shard step): its tier-2 list reads as empty and its tier-2 flags as clear unless
+    // something is written later.  (Atomic stores: they reach L2 in order with the atomicOr of flag_tier2.)
+    unsigned *const my_ovf = a.ovf + (int64_t)blockIdx.x * a.ovf_words;
+    for (int w = lane; w < a.ovf_words; w += 64) __hip_atomic_store(&my_ovf[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) a.cand_count[(int64_t)q * a.lists_per_q + a.n_splits + split] = 0;
     if (nt == 0 || tier1_cannot_serve(ix, nt, k, tpu, a.dbg)) {  // tier 2 serves it
         if (lane == 0) {
             a.cand_count[list] = 0;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
     int sink = 0;            // DBG only
     const int dbg = DBG ? a.dbg : 0;
 #ifdef SRX_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
     unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     bool flagged = false;    // wave-uniform: some unit of this block was handed to tier 2
@@ -144,22 +151,108 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         int64_t tblk = 0;
         unsigned skip_boff = 0;  // BYTE offset of my term's skip row (the table is < 4 GiB: tier1_cannot_serve): one VGPR, and the
                                  // loads take the table's base from SGPRs (global_load ... v_off, s[base])
-        float my_idf = 0.f, my_qw = 0.f;
-        if (has_term) {
+        float my_idf = 0.f, my_qw = 0.f, my_bnd = 0.f;
+        constexpr int NBQ = SRX_W_DEPTH + 2;
+        int bq[NBQ];             // bq[i] = boundary (next unit to issue) + i of my term, in padded postings
+        const int col = bound_column(k);
+        const bool use_bound = ix.term_bound != nullptr && col >= 0;
+        constexpr bool SCALAR_PROLOGUE = LPT_LOG2 >= 3;  // <= 8 term slots
+        if constexpr (SCALAR_PROLOGUE) {
+            // Everything a query needs before its first posting load -- its terms, their weights, run starts, idf, score
+            // bounds and first unit boundaries -- is WAVE-UNIFORM data (one value per term, <= 8 terms).  It is read with
+            // SCALAR loads: they do not queue behind the ~40 KB of posting loads the CU's other waves keep in the vector memory
+            // pipeline, which made each of the four dependent round trips of this prologue cost about as much as a whole
+            // unit (the stamps: 20 % of a wave's time on a 1.25 M-doc shard).  The values reach the term's lane group
+            // through one compare + select per term.
+            constexpr int NTS = 64 >> LPT_LOG2;
+            // the NTS term ids and weights: one wide scalar load each (slots >= nt read the next queries' terms -- valid ids,
+            // never used: has_term); the batch's last queries, where that would run past the arrays, repeat their last term
+            int s_term[NTS];
+            float s_qwt[NTS];
+            typedef int srx_ivec __attribute__((ext_vector_type(NTS < 2 ? 2 : NTS), aligned(4)));
+            typedef float srx_fvec __attribute__((ext_vector_type(NTS < 2 ? 2 : NTS), aligned(4)));
+            if (t0 + (NTS < 2 ? 2 : NTS) <= n_terms_all) {  // uniform
+                const srx_ivec tv = *(const SRX_CONSTANT srx_ivec *)(a.q_term + t0);
+                const srx_fvec wv = *(const SRX_CONSTANT srx_fvec *)(a.q_weight + t0);
+#pragma unroll
+                for (int i = 0; i < NTS; ++i) {
+                    s_term[i] = tv[i];
+                    s_qwt[i] = wv[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NTS; ++i) {
+                    s_term[i] = cload_i32(a.q_term + t0 + min(i, nt - 1));
+                    s_qwt[i] = cload_f32(a.q_weight + t0 + min(i, nt - 1));
+                }
+            }
+            // (value & m) | (old & ~m) with m = all ones in the term's lanes: one v_bfi per value.  Written with selects the
+            // compiler sinks every scalar load into a branch on `mine` and waits for it there: eight round trips in a row.
+            auto pick = [](unsigned m, unsigned x, unsigned old) __attribute__((always_inline)) { return (x & m) | (old & ~m); };
+            unsigned v_tlo = 0, v_thi = 0, v_idf = 0, v_qw = 0, v_bnd = 0, v_bq[2] = {0u, 0u};
+            // Batches of <= 4 terms: all scalar loads of a batch are issued before the first one is waited for (scalar loads
+            // return out of order, so a wait is always for all of them; ~7 SGPRs per term -- with all 8 terms in one batch the
+            // allocator spills SGPRs, and a spill waits for its load).  Only the first TWO unit boundaries come this way; the
+            // later ones are loaded by the lanes themselves and arrive behind the first unit's postings.
+            constexpr int TB = NTS < 4 ? NTS : 4;
+            auto batches = [&](auto with_bound) __attribute__((always_inline)) {  // two instances: no branch sits between the loads of a batch
+                constexpr bool WB = decltype(with_bound)::value != 0;
+#pragma unroll
+                for (int h = 0; h < NTS; h += TB) {
+                    int64_t s_tp[TB];
+                    float s_idf[TB], s_b[TB];
+                    int s_q0[TB], s_q1[TB];
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        const int ti = s_term[h + j];
+                        s_tp[j] = cload_i64(ix.term_ptr + ti);
+                        s_idf[j] = cload_f32(ix.idf + ti);
+                        s_b[j] = WB ? cload_f32(ix.term_bound + (int64_t)ti * 4 + col) : 0.0f;
+                        s_q0[j] = cload_i32(ix.tile_skip + (int64_t)ti * row + min(su_lo * tpu, ix.n_tiles));
+                        s_q1[j] = cload_i32(ix.tile_skip + (int64_t)ti * row + min((su_lo + 1) * tpu, ix.n_tiles));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        const int ti = s_term[h + j];
+                        const unsigned m = tslot == h + j ? 0xFFFFFFFFu : 0u;
+                        const int64_t tb = s_tp[j] >> 2;
+                        v_tlo = pick(m, (unsigned)(tb & 0xFFFFFFFFll), v_tlo);
+                        v_thi = pick(m, (unsigned)(tb >> 32), v_thi);
+                        skip_boff = pick(m, ((unsigned)ti * (unsigned)row) << 2, skip_boff);
+                        v_idf = pick(m, __float_as_uint(s_idf[j]), v_idf);
+                        v_qw = pick(m, __float_as_uint(s_qwt[h + j]), v_qw);
+                        v_bnd = pick(m, __float_as_uint(s_b[j]), v_bnd);
+                        v_bq[0] = pick(m, (unsigned)s_q0[j], v_bq[0]);
+                        v_bq[1] = pick(m, (unsigned)s_q1[j], v_bq[1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (use_bound)
+                batches(IntC<1>{});
+            else
+                batches(IntC<0>{});
+            bq[0] = (int)v_bq[0];
+            bq[1] = (int)v_bq[1];
+            tblk = (int64_t)(((unsigned long long)v_thi << 32) | v_tlo);
+            my_idf = __uint_as_float(v_idf);
+            my_qw = __uint_as_float(v_qw);
+            my_bnd = __uint_as_float(v_bnd);
+        } else if (has_term) {
             const int term = a.q_term[t0 + tslot];
             tblk = ix.term_ptr[term] >> 2;
             skip_boff = ((unsigned)term * (unsigned)row) << 2;
             my_idf = ix.idf[term];
             my_qw = a.q_weight[t0 + tslot];
+            if (use_bound) my_bnd = ix.term_bound[(int64_t)term * 4 + col];
         }
         // Initial threshold: with all query idf >= 0 a doc's score is at least any single contribution, so the K-th
         // largest contribution of any one term (K >= k, from the index's term_bound table) is an exact lower bound
         // on this shard's k-th best score.  Candidates below it can be dropped from the very first unit.
         {
-            const int col = bound_column(k);
             float bnd = 0.0f;
-            if (ix.term_bound != nullptr && col >= 0 && has_term && my_idf > 0.0f && my_qw > 0.0f)
-                bnd = 0.0f + (ix.term_bound[(int64_t)a.q_term[t0 + tslot] * 4 + col] * my_idf) * my_qw;
+            if (use_bound && has_term && my_idf > 0.0f && my_qw > 0.0f) bnd = 0.0f + (my_bnd * my_idf) * my_qw;
             const bool neg = has_term && (my_idf < 0.0f || my_qw < 0.0f);
             const unsigned t0bits = wave_max(__float_as_uint(bnd > 0.0f ? bnd : 0.0f));
             tk.tau = (__ballot(neg) != 0ull) ? 0u : uniu(t0bits);
@@ -334,6 +427,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                             S.ldoc[pz] = ubase + (int)slot_id(d, r);
                         }
                         tk.count += n2;
+#ifdef SRX_STAMP
+                        st_cnt[5] += n2;
+#endif
                     }
                 }
             }
@@ -342,7 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         };
 
         auto flag_tier2 = [&](int su) __attribute__((always_inline)) {
-            if (lane == 0) atomicOr(&a.ovf[(int64_t)q * a.ovf_words + (su >> 5)], 1u << (su & 31));
+            if (lane == 0) atomicOr(&my_ovf[su >> 5], 1u << (su & 31));
             flagged = true;
         };
 
@@ -377,8 +473,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             return false;
         };
         // issue unit su's loads into (d, v); returns its step count (see score; a run that does not fit loads nothing)
-        constexpr int NBQ = SRX_W_DEPTH + 2;
-        int bq[NBQ];  // bq[i] = boundary (next unit to issue) + i, in padded postings
         int su_issue = su_lo;
         auto fetch = [&](unsigned (&d)[W_RP], float (&v)[W_R]) __attribute__((always_inline)) -> int {
             const int len = (has_term && su_issue < su_hi) ? (bq[1] - bq[0]) >> 2 : 0;  // blocks
@@ -401,10 +495,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         // warms up and hardly ever after.
         constexpr int DEPTH = SRX_W_DEPTH;
         int su_start = su_lo;
+        STAMP(8);  // prologue: item decode, bitmap clear, term metadata, initial threshold
         for (;;) {
             su_issue = su_start;
+            const bool first_start = SCALAR_PROLOGUE && su_start == su_lo;  // uniform: bq[0], bq[1] came with the scalar prologue
 #pragma unroll
-            for (int i = 0; i < NBQ; ++i) bq[i] = bound(su_start + i);
+            for (int i = 0; i < NBQ; ++i) {
+                const int bi = bound(su_start + i);
+                bq[i] = (i < 2 && first_start) ? bq[i] : bi;
+            }
             unsigned dS[DEPTH][W_RP];
             float vS[DEPTH][W_R];
             int st[DEPTH];  // uniform: load steps of the unit in set j (see score)
@@ -422,6 +521,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 }
             }
             if (su_full < 0) break;
+            STAMP(0);
+            CNT(4);
             // ---- no register set is live here: shrink the list to its k best (tau rises) and redo unit su_full.  A unit that
             //      does not fit next to a list of k entries either goes to tier 2 ----
             if (tk.count > (unsigned)k) {
@@ -432,6 +533,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
                 flag_tier2(su_full);
                 su_start = su_full + 1;
             }
+            STAMP(9);  // list selection between restarts
         }
     };
     switch (6 - lg) {
@@ -450,13 +552,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
         wave_list_select(S, count, k);
         count = (unsigned)k;
     }
-#ifdef SRX_STAMP
     STAMP(7);  // epilogue (final select)
-    if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
-        atomicAdd(&g_stamp[8], 1ull);
-        for (int i = 0; i < 7; ++i) atomicAdd(&g_stamp[9 + i], (unsigned long long)st_cnt[i]);
-    }
+#ifdef SRX_STAMP
+#define STAMP_FLUSH()                                                                              \
+    do {                                                                                           \
+        STAMP(10); /* rank + row / list write */                                                   \
+        if (lane == 0) {                                                                           \
+            for (int i = 0; i < 12; ++i) atomicAdd(&g_stamp[i], st_acc[i]);                        \
+            atomicAdd(&g_stamp[12], 1ull);                                                         \
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[13 + i], (unsigned long long)st_cnt[i]); \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP_FLUSH() \
+    do {              \
+    } while (0)
 #endif
     if (nsq == 1 && !flagged && a.out_doc != nullptr) {
         // This wave holds the query's complete top-k (one split, nothing handed to tier 2): rank it here and write
@@ -467,17 +577,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
             a.out_count[(int64_t)q * a.out_cnt_stride] = (int)count;
             a.cand_count[list] = -1;  // tells the merge kernel this query is final
         }
+        STAMP_FLUSH();
         return;
     }
+    // A split's list is read by another wave of this grid (below), possibly on another XCD with an L2 of its own: its
+    // entries are written and read with agent-scope (memory-coherent) accesses.  NO agent-scope fence: on this chip that is
+    // a write-back / invalidate of the XCD's whole L2 -- 2 352 of them per C3 batch made the kernel 70 us slower.
     const int64_t o = list * k;
     for (unsigned i = lane; i < count; i += 64) {
-        a.cand_doc[o + i] = S.ldoc[i];
-        a.cand_score[o + i] = __uint_as_float(S.lbits[i]);
+        __hip_atomic_store(&a.cand_doc[o + i], S.ldoc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned *>(&a.cand_score[o + i]), S.lbits[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) {
-        a.cand_count[list] = (int)count;
+        __hip_atomic_store(&a.cand_count[list], (int)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (flagged) a.work[1 + atomicAdd(&a.work[0], 1)] = (int)blockIdx.x;
     }
+    if (nsq > 1 && a.done != nullptr && a.out_doc != nullptr) {
+        // A split query: the split that finishes LAST merges the query's lists here -- while the other waves of the grid
+        // are still scoring -- unless some split left units to tier 2 (then the merge kernel does it after tier 2).
+        // done[q] counts arrivals in its low half and flagged splits in its high half.  The workgroup-scope release is a
+        // wait for this wave's stores (write-through, straight to memory) before the counter moves.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(&a.done[q - a.n_whole], 1u + (flagged ? 0x10000u : 0u));
+        old = uniu(old);
+        if ((old & 0xFFFFu) + 1u == (unsigned)nsq && (old >> 16) == 0u && !flagged) {
+            const int64_t l0 = (int64_t)q * a.lists_per_q;  // the query's tier-1 lists: l0 .. l0 + nsq - 1
+            for (int s2 = 0; s2 < nsq; ++s2) {              // uniform loop; my own list is already in LDS
+                if (s2 == split) continue;
+                const unsigned c2 = (unsigned)min(max(__hip_atomic_load(&a.cand_count[l0 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0), k);
+                if (count + c2 > (unsigned)WaveShared2::LCAP) {  // k + k <= LCAP (k <= 112): after a selection there is room
+                    wave_list_select(S, count, k);
+                    count = (unsigned)k;
+                }
+                for (unsigned i = lane; i < c2; i += 64) {
+                    S.ldoc[count + i] = __hip_atomic_load(&a.cand_doc[(l0 + s2) * k + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S.lbits[count + i] = __hip_atomic_load(reinterpret_cast<const unsigned *>(&a.cand_score[(l0 + s2) * k + i]), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                count += c2;
+                wsync();
+            }
+            if (count > (unsigned)k) {
+                wave_list_select(S, count, k);
+                count = (unsigned)k;
+            }
+            wave_rank_emit(S, reinterpret_cast<unsigned long long *>(S.bm), count, k, a.doc_base, a.out_doc + (int64_t)q * a.out_row_stride,
+                           a.out_score + (int64_t)q * a.out_row_stride);
+            if (lane == 0) {
+                a.out_count[(int64_t)q * a.out_cnt_stride] = (int)count;
+                a.cand_count[l0] = -1;  // final: the merge kernel skips the query
+            }
+        }
+    }
+    STAMP_FLUSH();
 }
 
 }  // namespace
@@ -502,8 +655,8 @@ int srx_launch_wave_kernel(const srx_wave_launch &a, int val_type, int64_t block
 
 #ifdef SRX_STAMP
 extern "C" __attribute__((visibility("default"))) int srx_debug_read_stamps(unsigned long long *h_out16) {
-    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16));
-    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32));
+    unsigned long long z[32] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
     return SRX_OK;
 }

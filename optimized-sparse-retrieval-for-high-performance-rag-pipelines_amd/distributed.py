@@ -16,6 +16,7 @@ tensor per batch, never per query.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -250,11 +251,16 @@ class ShardedSearcher:
         if overlap:
             self._step = getattr(self, "_step", 0) + 1
             slot = self._step & 1
-            main = torch.cuda.current_stream(dev)
+            cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:
+                # Two streams of the searcher's own: the scoring of batch i + 1 and the exchange of batch i only run side by
+                # side when NEITHER is the legacy default stream (measured, profiles/r03_exchange_timeline_*: with the search
+                # on the default stream every kernel of both streams ran back to back, the "overlap" only added event waits)
+                self._score = torch.cuda.Stream(device=dev)
                 self._side = torch.cuda.Stream(device=dev)
                 self._slot_ev = {}
-            side = self._side
+            main, side = self._score, self._side
+            main.wait_stream(cur)  # the caller's query tensors
             ev_prev = self._slot_ev.get(slot)
             if ev_prev is not None:
                 main.wait_event(ev_prev)  # the exchange that last used this slot's buffers has finished
@@ -281,7 +287,8 @@ class ShardedSearcher:
                                          torch.empty((world, nq, row), dtype=torch.int32, device=dev))
             mine, recv = bufs
             send = mine
-            self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
+            with (torch.cuda.stream(main) if overlap else contextlib.nullcontext()):
+                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
         else:
             blk = (nq + world - 1) // world
             key = ("pa2a", world, nq, k, dev, slot)
@@ -291,7 +298,8 @@ class ShardedSearcher:
                                          torch.empty((world, blk, row), dtype=torch.int32, device=dev))   # the lists of my query block
             send, recv = bufs
             mine = send[:nq]
-            self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
+            with (torch.cuda.stream(main) if overlap else contextlib.nullcontext()):
+                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
         if not overlap:
             out = exchange(mine, send, recv)
         else:
@@ -303,7 +311,9 @@ class ShardedSearcher:
                 done = torch.cuda.Event()
                 done.record(side)
             self._slot_ev[slot] = done
-            out.record_stream(main)  # allocated on the side stream, consumed by the caller on the main stream
+            out.record_stream(cur)  # allocated on the side stream, consumed by the caller on its own stream after wait()
+            for t in (q_ptr, q_term, q_weight):
+                t.record_stream(main)
         return out[:, :k], out[:, k:2 * k].view(torch.float32), out[:, 2 * k]
 
     def wait(self) -> None:

@@ -11,13 +11,15 @@ try:
 except SystemExit:
     pass
 L = _capi.lib()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 L.srx_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 L.srx_debug_read_stamps(out)
-names = ["loop / previous tail", "issue", "wait data + pass 1", "multi-term docs", "restore", "screening", "candidates", "epilogue"]
-tot = sum(out[i] for i in range(8))
-print("waves:", out[8], "ticks/wave:", tot / max(out[8], 1))
-w = max(out[8], 1)
-print(f"per wave: units {out[9]/w:.1f}  units with multi-term docs {out[10]/w:.1f}  docs resolved {out[11]/w:.1f}  screening triggers {out[12]/w:.1f}")
+names = ["loop / previous tail", "issue", "wait data + pass 1", "multi-term docs", "restore", "screening", "candidates", "final select",
+         "prologue", "restart selections", "rank + row write", "-"]
+tot = sum(out[i] for i in range(12))
+w = max(out[12], 1)
+print("waves:", out[12], "ticks/wave:", tot / w, "(100 MHz ticks: %.1f us per wave)" % (tot / w / 100.0))
+c = [out[13 + i] / w for i in range(8)]
+print(f"per wave: units {c[0]:.1f}  units with multi-term docs {c[1]:.1f}  docs resolved {c[2]:.1f}  screening triggers {c[3]:.1f}  restarts {c[4]:.2f}  single-term candidates appended {c[5]:.1f}")
 for i, n in enumerate(names):
-    print(f"{n:28s} {100.0 * out[i] / tot:6.2f} %   {out[i] / max(out[8],1):12.0f} ticks/wave")
+    print(f"{n:28s} {100.0 * out[i] / tot:6.2f} %   {out[i] / w:12.0f} ticks/wave")
