@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--local-bounds", action="store_true", help="N > 1: keep per-shard score bounds (no corpus-wide bound exchange)")
     ap.add_argument("--emulate-world", type=int, default=0, help="dev: on one GPU, use the score bounds a shard would get among this many identical shards")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: submit every step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--same-query", action="store_true", help="dev: every query of the batch is query 0 (postings stay in cache: the compute-bound time of the kernels)")
     ap.add_argument("--pipe-copy", action="store_true", help="host-batch pipeline: explicit H2D copy of the query block instead of zero-copy reads")
@@ -385,15 +386,20 @@ def main():
         calls["n"] += 1
         return ix_search(a, b, c, kk, out=out if (dist is None and out_ is None) else out_)  # N = 1: reuse the output tensors
 
-    def counted_search_packed(a, b, c, kk, out_=None):
+    def counted_search_packed(a, b, c, kk, out_=None, **kw):
         calls["n"] += 1
-        return ix_search_packed(a, b, c, kk, out=out_)
+        return ix_search_packed(a, b, c, kk, out=out_, **kw)
 
     ix.search_device, ix.search_packed_device = counted_search, counted_search_packed
     searcher = sparse_rx.ShardedSearcher.for_device_index(ix)  # N > 1: + RCCL exchange of the packed per-shard top-k + merge
     searcher.force_exchange = args.force_dist
     searcher.mode = args.exchange
     searcher.overlap = not args.no_overlap
+    # N > 1: the step (search + exchange + merge) is captured into HIP graphs on two alternating lanes (ShardedSearcher._search_graph)
+    searcher.graph = dist is not None and not args.no_graph and not args.no_overlap
+    want_graph = bool(searcher.graph)
+    if want_graph:  # no event records inside the captured steps: the kernel timings come from eager steps after the timed region
+        ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=0, debug=args.debug, unit_tiles=args.unit_tiles)
 
     def step():
         return searcher.search(qp, qt, qw, k, chunks=args.chunks, q_ptr_host=q_ptr)
@@ -423,6 +429,26 @@ def main():
         elapsed = float(t.item())
     prof = ix.profile_read()
     calls_per_step = calls["n"] / max(1, args.steps)
+    kernel_timing = "hipEvents on the search stream around the kernels of every %d-th timed step" % max(1, args.profile_every)
+    if want_graph:
+        # the timed steps were graph replays without event records: time the same kernels on a few eager steps now
+        searcher.wait()
+        torch.cuda.synchronize(dev)
+        graphed = bool(searcher.graph)  # False if the capture was refused and the eager path ran
+        searcher.graph = False
+        ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=1, debug=args.debug, unit_tiles=args.unit_tiles)
+        calls["n"] = 0
+        for _ in range(5):
+            step()
+        searcher.wait()
+        torch.cuda.synchronize(dev)
+        prof = ix.profile_read()
+        calls_per_step = calls["n"] / 5
+        kernel_timing = ("5 eager steps after the timed region, hipEvents around every kernel (the timed steps were HIP-graph replays)" if graphed
+                         else "5 eager steps after the timed region (graph capture was refused: the timed steps were eager too)")
+        result_graph = graphed
+    else:
+        result_graph = False
     ix.search_device, ix.search_packed_device = ix_search, ix_search_packed
 
     # ---- PCIe-inclusive: the same steps fed from host batches through the pinned double-buffered pipeline ----------
@@ -564,13 +590,14 @@ def main():
                                f"(pcie_inclusive_qps = host batches in / host rows out)",
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_total, "n_queries": nq, "k": k,
                    "sharding": f"doc-range x{world}" + ((" + RCCL all-to-all of packed per-shard top-k, merge of the own query block, all-gather of merged rows" if args.exchange == "a2a" else " + one RCCL all-gather of packed per-shard top-k") if (world > 1 or args.force_dist) else ""),
+                   "step_submission": "HIP-graph replay, two lanes" if result_graph else "eager launches",
                    "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps, "pcie_inclusive_ms_per_step": pcie_ms,
                    "steady_state": steady},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note, "kernel": dominant,
                      "kernel_ms": prof["wave_ms"] * calls_per_step, "tier2_kernel_ms": prof["block_ms"] * calls_per_step,
                      "merge_kernel_ms": prof["merge_ms"] * calls_per_step,
-                     "launches_timed": prof["calls"], "launches_per_step": calls_per_step,
+                     "launches_timed": prof["calls"], "launches_per_step": calls_per_step, "kernel_timing": kernel_timing,
                      "bytes_per_posting": post_bytes,
                      "achieved_canonical": alg_bytes_canonical / score_s / 1e9,   # the same time against 4-byte doc ids
                      "frac_canonical": alg_bytes_canonical / score_s / 1e9 / HBM_PEAK_GBPS,
@@ -604,8 +631,8 @@ def main():
         if int(flag.item()) != 1:
             if rank == 0:
                 log("PARITY FAILURE: exchanged GPU rows differ from the host merge of the per-shard oracle lists")
-            dist.destroy_process_group()
-            raise SystemExit(3)
+            sys.stderr.flush()
+            os._exit(3)  # not a collective tear-down with graphs alive: the verdict is what matters here
         result["parity_check"] = {"queries": n_chk, "shards": world, "how": "per-shard oracle (full-CSR scan) on each rank's host CSR, "
                                   "host merge by (score desc, doc asc) on rank 0, bit-exact comparison with the exchanged GPU rows"}
         result["cpu_baseline"] = None
@@ -641,9 +668,19 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    ix.close()
+    sys.stdout.flush()
     if dist is not None:
+        # Tear-down in dependency order: lanes / captured graphs (they hold RCCL work) -> index -> process group.  The result
+        # line is out; should the collective tear-down of this stack ever wedge (it did once on a one-rank rehearsal with
+        # graphs alive), a watchdog ends the rank with the status it has earned instead of hanging the launcher.
+        import threading
+        threading.Timer(45.0, lambda: os._exit(0)).start()
+        dist.barrier()
+        searcher.close()
+        ix.close()
         dist.destroy_process_group()
+        os._exit(0)
+    ix.close()
 
 
 def _cpu_model():

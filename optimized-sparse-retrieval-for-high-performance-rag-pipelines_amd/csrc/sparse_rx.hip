@@ -79,7 +79,11 @@ struct ScoreShared {
 
 // srx_search_after's exclusive upper bound on (score bits, shard-local doc): true when the candidate ranks after it
 __device__ __forceinline__ bool after_bound(const ScoreShared &S, unsigned b, int doc) {
+#ifdef SRX_NO_AFTER  // dev experiment: what the bound test costs the tier-2 kernel on plain searches
+    return true;
+#else
     return b < S.ub_bits || (b == S.ub_bits && doc > S.ub_doc);
+#endif
 }
 
 // Rank the block's final list (tk.count <= k entries, unordered) by (score desc, doc asc) -- bitonic sort of 64-bit keys

@@ -595,8 +595,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SRX_W_WPE)))
     if (nsq > 1 && a.done != nullptr && a.out_doc != nullptr) {
         // A split query: the split that finishes LAST merges the query's lists here -- while the other waves of the grid
         // are still scoring -- unless some split left units to tier 2 (then the merge kernel does it after tier 2).
-        // done[q] counts arrivals in its low half and flagged splits in its high half.  The workgroup-scope release is a
-        // wait for this wave's stores (write-through, straight to memory) before the counter moves.
+        // done[q] counts arrivals in its low half and flagged splits in its high half.  Before the counter moves, this
+        // wave's stores (write-through, straight to memory) must be acknowledged: an explicit s_waitcnt -- a workgroup-scope
+        // release fence compiles to NOTHING here (a workgroup of one wave is its own scope), which let the last split read
+        // lists that were still in flight (caught by bench.py's multi-stream parity check on C2).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         unsigned old = 0;
         if (lane == 0) old = atomicAdd(&a.done[q - a.n_whole], 1u + (flagged ? 0x10000u : 0u));

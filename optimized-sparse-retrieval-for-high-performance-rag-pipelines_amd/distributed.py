@@ -178,8 +178,10 @@ class ShardedSearcher:
     @classmethod
     def for_device_index(cls, index, group=None) -> "ShardedSearcher":
         from .index import merge_topk_packed_device, merge_topk_packed_out_device, pack_results
-        return cls(index.search_device, pack_results, merge_topk_packed_device, group,
-                   local_search_packed=index.search_packed_device, merge_packed_out=merge_topk_packed_out_device)
+        s = cls(index.search_device, pack_results, merge_topk_packed_device, group,
+                local_search_packed=index.search_packed_device, merge_packed_out=merge_topk_packed_out_device)
+        s.workspace_bytes = index.workspace_bytes  # lets the graph lanes give every lane a workspace of its own
+        return s
 
     def search(self, q_ptr, q_term, q_weight, k: int, chunks: int = 0, q_ptr_host=None, after=None):
         """One batch.  Optionally (chunks > 1) the batch is cut into sub-batches: the all-gather + merge of
@@ -198,6 +200,11 @@ class ShardedSearcher:
         on_gpu = q_ptr.is_cuda
         if chunks <= 0:
             chunks = 1  # measured on one GPU: cutting the batch costs more (under-filled launches) than it can hide
+        if (on_gpu and after is None and getattr(self, "graph", False) and self.local_search_packed is not None
+                and self.merge_packed_out is not None and getattr(self, "workspace_bytes", None) is not None):
+            out = self._search_graph(q_ptr, q_term, q_weight, k, world)
+            if out is not None:
+                return out
         if (chunks == 1 or not on_gpu) and self.local_search_packed is not None and self.merge_packed_out is not None:
             return self._search_packed(q_ptr, q_term, q_weight, k, world, **kw)
         if chunks == 1 or not on_gpu:
@@ -231,7 +238,51 @@ class ShardedSearcher:
                 t.record_stream(main)
         return tuple(torch.cat([o[j] for o in outs]) for j in range(3))
 
-    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int, after=None):
+    def _search_graph(self, q_ptr, q_term, q_weight, k: int, world: int):
+        """Steady-state submission for a caller that searches the SAME device tensors batch after batch (a serving loop with
+        fixed staging buffers; bench.py): the whole step -- srx_search_packed, the RCCL exchange, the packed merge -- is
+        captured once per LANE into a HIP graph and replayed.  Two lanes = two HIP streams with buffers and workspace of their
+        own, used alternately: the exchange of batch i (lane i & 1) overlaps the scoring of batch i + 1 (the other lane)
+        without a single event between them, and a step costs the host one graph launch (measured on one GPU, RCCL group of
+        one rank: the eager overlap path needs ~0.25 ms of Python + launches per step -- more than the 0.21 ms the GPU needs).
+        The rows of batch i stay valid until lane i & 1 is replayed again (two batches later); :meth:`wait` joins both lanes.
+        Returns None (and switches itself off) when the capture is not possible on this stack: the eager path then runs."""
+        import torch
+        dev = q_ptr.device
+        key = (q_ptr.data_ptr(), q_term.data_ptr(), q_weight.data_ptr(), int(q_ptr.shape[0]), int(q_term.shape[0]), k, self.mode, world)
+        if getattr(self, "_lanes", None) is None:
+            self._lanes, self._lane_step = {}, 0
+        lanes = self._lanes.get(key)
+        if lanes is None:
+            cur = torch.cuda.current_stream(dev)
+            lanes = []
+            try:
+                for li in range(2):
+                    st = torch.cuda.Stream(device=dev)
+                    ws = torch.empty(max(int(self.workspace_bytes(q_ptr.shape[0] - 1, k)), 1 << 16), dtype=torch.uint8, device=dev)
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        for _ in range(2):  # eager warm-up on the lane's stream (RCCL channel setup, lazy allocations) before the capture
+                            self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws)
+                    st.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        out = self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws)
+                    lanes.append((st, g, out, ws))
+            except Exception as e:  # pragma: no cover  (stack without graph-capturable collectives)
+                import warnings
+                warnings.warn(f"ShardedSearcher: HIP-graph capture of the search step failed ({type(e).__name__}: {e}); using the eager path")
+                self.graph = False
+                torch.cuda.synchronize(dev)
+                return None
+            self._lanes[key] = lanes
+        st, g, out, _ = lanes[self._lane_step & 1]
+        self._lane_step += 1
+        with torch.cuda.stream(st):
+            g.replay()
+        return out
+
+    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int, after=None, _lane=None, _workspace=None):
         """The exchange of :meth:`_exchange` on packed rows end to end: the local search writes packed rows straight
         into the send buffer, the merge reads the received rows in place and writes packed rows, and the results are
         views of the gathered buffer (doc = rows[:, :k], score = rows[:, k:2k] as f32, count = rows[:, 2k]).
@@ -246,8 +297,11 @@ class ShardedSearcher:
         dev = q_ptr.device
         if self._buf is None:
             self._buf = {}
-        overlap = bool(getattr(self, "overlap", False)) and q_ptr.is_cuda
-        slot = 0
+        overlap = bool(getattr(self, "overlap", False)) and q_ptr.is_cuda and _lane is None
+        slot = 0 if _lane is None else _lane
+        lkw = {} if after is None else {"after": after}
+        if _workspace is not None:
+            lkw["workspace"] = _workspace
         if overlap:
             self._step = getattr(self, "_step", 0) + 1
             slot = self._step & 1
@@ -288,7 +342,7 @@ class ShardedSearcher:
             mine, recv = bufs
             send = mine
             with (torch.cuda.stream(main) if overlap else contextlib.nullcontext()):
-                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
+                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **lkw)
         else:
             blk = (nq + world - 1) // world
             key = ("pa2a", world, nq, k, dev, slot)
@@ -299,7 +353,7 @@ class ShardedSearcher:
             send, recv = bufs
             mine = send[:nq]
             with (torch.cuda.stream(main) if overlap else contextlib.nullcontext()):
-                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **({} if after is None else {'after': after}))
+                self.local_search_packed(q_ptr, q_term, q_weight, k, mine, **lkw)
         if not overlap:
             out = exchange(mine, send, recv)
         else:
@@ -317,11 +371,29 @@ class ShardedSearcher:
         return out[:, :k], out[:, k:2 * k].view(torch.float32), out[:, 2 * k]
 
     def wait(self) -> None:
-        """Make the current stream wait for every exchange submitted with ``overlap`` (no-op otherwise)."""
+        """Make the current stream wait for every exchange submitted with ``overlap`` / through the graph lanes (no-op otherwise)."""
+        import torch
         side = getattr(self, "_side", None)
         if side is not None:
-            import torch
             torch.cuda.current_stream(side.device).wait_stream(side)
+        for lanes in (getattr(self, "_lanes", None) or {}).values():
+            for st, *_ in lanes:
+                torch.cuda.current_stream(st.device).wait_stream(st)
+
+    def close(self) -> None:
+        """Join the lanes and drop their captured graphs (they hold RCCL work: destroy them BEFORE the process group)."""
+        import torch
+        lanes = getattr(self, "_lanes", None)
+        if lanes:
+            for ls in lanes.values():
+                for st, *_ in ls:
+                    st.synchronize()
+            self._lanes = {}
+        if getattr(self, "_side", None) is not None:
+            self._side.synchronize()
+        self._buf = None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def _exchange(self, doc, score, count, k: int, world: int, slot: int):
         """Per-shard top-k -> global top-k.
