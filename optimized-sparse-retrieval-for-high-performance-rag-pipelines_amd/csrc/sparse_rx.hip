@@ -78,12 +78,12 @@ struct ScoreShared {
 };
 
 // srx_search_after's exclusive upper bound on (score bits, shard-local doc): true when the candidate ranks after it
+// AFTER = false is the instance plain searches run: the test (two LDS reads + compares wherever a candidate is formed)
+// measured 5.5 % of a C4 batch and 4 % of a C5 batch (profiles/r03_ab_tier2_after_bound.log).
+template <bool AFTER>
 __device__ __forceinline__ bool after_bound(const ScoreShared &S, unsigned b, int doc) {
-#ifdef SRX_NO_AFTER  // dev experiment: what the bound test costs the tier-2 kernel on plain searches
-    return true;
-#else
+    if constexpr (!AFTER) return true;
     return b < S.ub_bits || (b == S.ub_bits && doc > S.ub_doc);
-#endif
 }
 
 // Rank the block's final list (tk.count <= k entries, unordered) by (score desc, doc asc) -- bitonic sort of 64-bit keys
@@ -136,7 +136,7 @@ struct Tier2Final {
 
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
 // scores into the running top-k.  nt = terms in this pass.
-template <typename VT>
+template <typename VT, bool AFTER>
 __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k, int dbg = 0) {
     const int tid = threadIdx.x;
     int *keys = reinterpret_cast<int *>(S.tbl);
@@ -212,7 +212,7 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned b = __float_as_uint(vs[c]);
-            const bool ok = ks[c] != EMPTY_KEY && vs[c] > 0.0f && b >= tau && after_bound(S, b, ks[c]);
+            const bool ok = ks[c] != EMPTY_KEY && vs[c] > 0.0f && b >= tau && after_bound<AFTER>(S, b, ks[c]);
             ubits[j * 4 + c] = ok ? b : 0u;
             udoc[j * 4 + c] = ks[c];
         }
@@ -346,7 +346,7 @@ constexpr int FLAT_SLOTS = 2048;               // doc hash slots of the grouping
 constexpr int FLAT_MPT = FLAT_MCAP / THREADS;  // 8
 constexpr int FLAT_MIN_TERMS = 12;             // below this the term-by-term paths are at least as good
 
-template <typename VT>
+template <typename VT, bool AFTER>
 __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_len, int tile_base, int k) {
     const int tid = threadIdx.x;
     unsigned *bm1 = S.tbl, *bm2 = S.tbl + 512;
@@ -415,7 +415,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
                 } else {
                     const float sc = 0.0f + c;
                     const unsigned b = __float_as_uint(sc);
-                    if (sc > 0.0f && b >= tau && after_bound(S, b, tile_base + d)) {
+                    if (sc > 0.0f && b >= tau && after_bound<AFTER>(S, b, tile_base + d)) {
                         ubits[n] = b;
                         udoc[n] = tile_base + d;
                     }
@@ -499,7 +499,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
                 last = best;
             }
             const unsigned bb = __float_as_uint(sum);
-            if (sum > 0.0f && bb >= tau && after_bound(S, bb, tile_base + (so_key[a] >> 8))) {
+            if (sum > 0.0f && bb >= tau && after_bound<AFTER>(S, bb, tile_base + (so_key[a] >> 8))) {
                 mbits[j] = bb;
                 mdoc[j] = tile_base + (so_key[a] >> 8);
             }
@@ -743,6 +743,7 @@ __device__ void list_compact_select(ScoreShared &S, int k, unsigned n_total, uns
 // one scan appends the candidates to the list and, past its capacity, to an overflow area; a selection then only touches
 // those ~1.4 k entries (list_compact_select), and only when the area is full.  The caller shrinks the list back into
 // tk (dense_list_flush) before anything else reads it.
+template <bool AFTER>
 __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_base, int k, int span_tiles = 1, int n_old_in = -1,
                                   int ovf_cap = 0) {
     const int tid = threadIdx.x;
@@ -766,7 +767,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
                 unsigned tot = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now && after_bound(S, __float_as_uint(a[c]), tile_base + 4 * i + c);
+                    ok[c] = a[c] > 0.0f && __float_as_uint(a[c]) >= tau_now && after_bound<AFTER>(S, __float_as_uint(a[c]), tile_base + 4 * i + c);
                     m[c] = __ballot(ok[c]);
                     tot += (unsigned)__popcll(m[c]);
                 }
@@ -832,7 +833,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
     auto cand_key = [&](int o) -> unsigned {  // key of accumulator o: its score bits when it can enter the list, else 0
         const float x = acc[o];
         const unsigned b = __float_as_uint(x);
-        return (x > 0.0f && b >= tau && after_bound(S, b, tile_base + o)) ? b : 0u;
+        return (x > 0.0f && b >= tau && after_bound<AFTER>(S, b, tile_base + o)) ? b : 0u;
     };
     unsigned mine = 0, lmx = 0, lmn = 0xFFFFFFFFu;
     for (int o = tid; o < n_valid; o += THREADS) {
@@ -927,7 +928,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
 #endif
 constexpr int DENSE_MIN = SRX_DENSE_MIN < HASH_CAP ? SRX_DENSE_MIN : HASH_CAP;  // a tile with more postings than this is accumulated densely
 
-template <typename VT>
+template <typename VT, bool AFTER>
 __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const int32_t *__restrict__ q_ptr,
                             const int32_t *__restrict__ q_term, const float *__restrict__ q_weight, int nq, int k,
                             int n_splits, int n_whole, int tpu, int n_super, int dbg, const unsigned *__restrict__ ovf,
@@ -1044,7 +1045,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                 __syncthreads();
                 T2(3); T2C(11);
-                if (!(dbg & 16384)) dense_tile_select(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old, OVF_CAP);
+                if (!(dbg & 16384)) dense_tile_select<AFTER>(S, ix, j0 << ix.tile_log2, k, WAVES, (dbg & 8192) ? -1 : n_old, OVF_CAP);
                 T2(4);
             }
             if (S.tk.count > (unsigned)KMAX)  // uniform (stable since the last barrier): the overflow area goes back to its owners
@@ -1076,7 +1077,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 }
                 __syncthreads();
                 T2(0);
-                served = flat_tile<VT>(S, ix, nt, my_len, su << ix.tile_log2, k);
+                served = flat_tile<VT, AFTER>(S, ix, nt, my_len, su << ix.tile_log2, k);
                 T2(1); T2C(9);
                 for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                 __syncthreads();
@@ -1089,7 +1090,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 }
                 __syncthreads();
                 T2(0);
-                hash_unit<VT>(S, ix, nt, my_len, k, dbg);
+                hash_unit<VT, AFTER>(S, ix, nt, my_len, k, dbg);
                 T2(2); T2C(10);
             } else if (P > 0 && wave_dense) {
                 dense_quads(su * tps, min(su * tps + tps, ix.n_tiles));
@@ -1144,14 +1145,14 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     __syncthreads();
                     if (GP <= (unsigned)DENSE_MIN) {
                         T2(0);
-                        hash_unit<VT>(S, ix, nt, glen, k, dbg);
+                        hash_unit<VT, AFTER>(S, ix, nt, glen, k, dbg);
                         T2(2); T2C(10);
                     } else {  // one dense tile (gb == ga + 1 by construction)
                         const int tile_base = ga << ix.tile_log2;
                         T2(0);
                         dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
                         T2(3); T2C(11);
-                        dense_tile_select(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);  // m_start / m_len are live: no overflow area
+                        dense_tile_select<AFTER>(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);  // m_start / m_len are live: no overflow area
                         T2(4);
                         for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                         __syncthreads();
@@ -1182,7 +1183,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 __syncthreads();
                 dense_tile_accumulate<VT>(S, ix, nt, tile_base, pass == 0);
             }
-            dense_tile_select(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);
+            dense_tile_select<AFTER>(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);
         }
     }
 
@@ -1226,7 +1227,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
 
 // Tier-2 kernel: a fixed grid of workgroups drains the worklist of (query, split) blocks that tier 1 could not
 // finish (flagged units, > 64 terms, k > 128).  work[0] = number of entries, work[1..] = block ids.
-template <typename VT>
+template <typename VT, bool AFTER>
 __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                                const int32_t *__restrict__ q_term,
                                                                const float *__restrict__ q_weight, int nq, int k,
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
     if (fin.hint != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fin.hint = n_work;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // the previous block's LDS state is dead
-        score_block<VT>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
+        score_block<VT, AFTER>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
                         ovf_words, lists_per_q, cand_doc, cand_score, cand_count, after_doc, after_score, doc_base, fin);
     }
 }
@@ -1755,14 +1756,16 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     const unsigned t2_grid = (unsigned)((hint == 0 && !t2_everything && t2_full > 128) ? 128 : t2_full);
     Tier2Final fin;
     fin.out_doc = out_doc; fin.out_score = out_score; fin.out_count = out_count; fin.ors = ors; fin.ocs = ocs; fin.hint = ix->d_hint;
-    if (ix->d.val_type == SRX_VAL_F32)
-        hipLaunchKernelGGL(srx_score_kernel<float>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base, fin);
-    else
-        hipLaunchKernelGGL(srx_score_kernel<__half>, dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term,
-                           q_weight, nq, k, p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q,
-                           work, cand_doc, cand_score, cand_count, after_doc, after_score, ix->d.doc_base, fin);
+#define SRX_LAUNCH_T2(VT, AFTER)                                                                                                  \
+    hipLaunchKernelGGL((srx_score_kernel<VT, AFTER>), dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term, q_weight, nq, k,   \
+                       p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q, work, cand_doc, cand_score, \
+                       cand_count, after_doc, after_score, ix->d.doc_base, fin)
+    if (ix->d.val_type == SRX_VAL_F32) {
+        if (after_score) SRX_LAUNCH_T2(float, true); else SRX_LAUNCH_T2(float, false);
+    } else {
+        if (after_score) SRX_LAUNCH_T2(__half, true); else SRX_LAUNCH_T2(__half, false);
+    }
+#undef SRX_LAUNCH_T2
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(ev[2], stream));
     // merge: only the SPLIT queries [n_whole, nq) have lists to merge (an unsplit query's final row was written by tier 1
