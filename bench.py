@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--local-bounds", action="store_true", help="N > 1: keep per-shard score bounds (no corpus-wide bound exchange)")
     ap.add_argument("--emulate-world", type=int, default=0, help="dev: on one GPU, use the score bounds a shard would get among this many identical shards")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the exchange of a batch with the scoring of the next one")
+    ap.add_argument("--keep-canonical", action="store_true",
+                    help="keep the canonical blocks (32-bit doc ids) resident next to the compact copy (default: one copy -- the compact one, read by both tiers)")
     ap.add_argument("--no-graph", action="store_true", help="N > 1: submit every step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: sub-batches whose exchange overlaps the next one's scoring (0 = auto)")
     ap.add_argument("--same-query", action="store_true", help="dev: every query of the batch is query 0 (postings stay in cache: the compute-bound time of the kernels)")
@@ -303,7 +305,8 @@ def main():
         if want_check:
             host_csr = sub
         ix = sparse_rx.DeviceIndex.from_csr(sub[0], sub[1], sub[2], idf_np, doc_lengths=sub[3], k1=1.2, b=0.75, avgdl=avgdl,
-                                            device=dev, doc_base=doc_base, tile_log2=args.tile_log2)
+                                            device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
+                                            keep_canonical=args.keep_canonical or bool(args.supertile_log2 or args.unit_tiles))
     else:
         chunk_docs = min(synth.CHUNK_DOCS, n_docs)
         n_chunks = (n_docs + chunk_docs - 1) // chunk_docs
@@ -360,7 +363,8 @@ def main():
         ix = sparse_rx.DeviceIndex.from_coo(rows, cols, tf, idf, shard_docs, doc_lengths=dl, k1=1.2, b=0.75, avgdl=avgdl,
                                             device=dev, doc_base=doc_base, tile_log2=args.tile_log2,
                                             unit_tiles=args.build_unit_tiles, mode="dot" if kind == "splade" else "bm25",
-                                            val_dtype="f16" if kind == "splade" else "f32")
+                                            val_dtype="f16" if kind == "splade" else "f32",
+                                            keep_canonical=args.keep_canonical or bool(args.supertile_log2 or args.unit_tiles))
         del rows, cols, tf  # (no empty_cache(): 288 GB of HBM, and freeing would idle the GPU before the timed region)
     ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=args.profile_every, debug=args.debug,
                 unit_tiles=args.unit_tiles)
@@ -492,7 +496,7 @@ def main():
     #      evaluate_rag_pipeline.py:741,779): `streams` slots, each with its own HIP stream, workspace and result rows,
     #      (a) device-resident batches, (b) host batches through the multi-stream HostBatchPipeline ----
     steady = None
-    n_streams = args.streams if args.streams > 0 else (4 if nq <= 2048 else 0)
+    n_streams = args.streams if args.streams > 0 else (4 if (nq <= 2048 and elapsed / args.steps < 0.5e-3) else 0)  # small, short batches only
     if dist is None and n_streams > 1:
         ix.set_opts(supertile_log2=args.supertile_log2, target_blocks=args.target_blocks, profile=False, debug=args.debug, unit_tiles=args.unit_tiles)
         n_b = max(200, 20 * args.steps)
@@ -539,7 +543,7 @@ def main():
     # canonical figure (4-byte doc ids) is reported next to it.
     n_post = int(df_local[qt.long()].sum().item())
     tier1_dominant = prof["wave_ms"] >= prof["block_ms"]
-    doc_bytes = 2 if (tier1_dominant and ix.post16 is not None) else 4
+    doc_bytes = 2 if (ix.post16 is not None and (tier1_dominant or ix.post is None)) else 4  # the copy the dominant kernel streams
     post_bytes = doc_bytes + ix.value_bytes
     alg_bytes = n_post * post_bytes + nq * k * 8
     alg_bytes_canonical = n_post * (4 + ix.value_bytes) + nq * k * 8
@@ -591,6 +595,7 @@ def main():
                    "n_docs": n_docs, "vocab": V, "nnz": nnz_total, "n_queries": nq, "k": k,
                    "sharding": f"doc-range x{world}" + ((" + RCCL all-to-all of packed per-shard top-k, merge of the own query block, all-gather of merged rows" if args.exchange == "a2a" else " + one RCCL all-gather of packed per-shard top-k") if (world > 1 or args.force_dist) else ""),
                    "step_submission": "HIP-graph replay, two lanes" if result_graph else "eager launches",
+                   "device_index_mb": round(ix.device_bytes() / 2 ** 20, 1), "posting_copies": "compact only" if ix.post is None else "canonical + compact",
                    "index_build_s": round(build_s, 2), "pcie_inclusive_qps": pcie_qps, "pcie_inclusive_ms_per_step": pcie_ms,
                    "steady_state": steady},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -136,12 +136,14 @@ struct Tier2Final {
 
 // Hash-accumulate the unit described by m_start/m_len (P <= HASH_CAP postings) and fold its positive
 // scores into the running top-k.  nt = terms in this pass.
-template <typename VT, bool AFTER>
-__device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k, int dbg = 0) {
+// CP: the index dropped its canonical blocks -- postings come from the compact copy (16-bit local ids + ubase = the unit's
+// first doc); every posting of a call then lies in ONE build unit (the host refuses unit overrides on such an index).
+template <typename VT, bool AFTER, bool CP>
+__device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_len, int k, int ubase, int dbg = 0) {
     const int tid = threadIdx.x;
     int *keys = reinterpret_cast<int *>(S.tbl);
     float *vals = reinterpret_cast<float *>(S.tbl + SLOTS);
-    const int32_t *post = ix.post;
+    const int32_t *post = CP ? ix.post16 : ix.post;
 
     // step table: term i contributes ceil(len_i / 256) steps
     const unsigned my_chunks = (tid < nt) ? (unsigned)((my_len + THREADS - 1) / THREADS) : 0u;
@@ -166,8 +168,8 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
                 const int p = S.st_off[s] + tid;
                 if (p < S.m_len[i]) {
                     const int64_t g = S.m_start[i] + p;
-                    d[r] = post_doc_at<VT>(post, g);  // sentinels (run padding) carry doc -1: skipped below
-                    v[r] = post_val_at(post, g, VT());
+                    d[r] = CP ? post16_doc_at<VT>(post, g, ubase) : post_doc_at<VT>(post, g);  // sentinels (run padding) read as negative docs: skipped below
+                    v[r] = CP ? post16_val_at(post, g, VT()) : post_val_at(post, g, VT());
                 }
             }
         }
@@ -223,13 +225,13 @@ __device__ void hash_unit(ScoreShared &S, const IndexView &ix, int nt, int my_le
 
 // Dense-accumulate one tile of G docs [tile_base, tile_base + G) described by m_start/m_len.
 // first_pass: zero the accumulators; last_pass: select.  (Queries with > MAXT terms take several passes.)
-template <typename VT>
-__device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int nt, int tile_base, bool first_pass) {
+template <typename VT, bool CP>
+__device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int nt, int tile_base, bool first_pass, int ubase) {
     const int tid = threadIdx.x;
     float *acc = reinterpret_cast<float *>(S.tbl);
     const int G = 1 << ix.tile_log2;
-    const int32_t *post = ix.post;
-    constexpr int BW = BlockWords<VT>::value;
+    const int32_t *post = CP ? ix.post16 : ix.post;
+    constexpr int BW = CP ? CompactWords<VT>::value : BlockWords<VT>::value;
     if (first_pass) {
         for (int i = tid; i < G / 4; i += THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
@@ -263,10 +265,16 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
             const int64_t blk = (p < span) ? b0 + (p >> 2) : b0;  // idle threads re-read the run's first block (always valid)
             int dd[4];
             float vv[4];
-            load_block(post + blk * BW, VT(), dd, vv);
+            if constexpr (CP)
+                load_block16(post + blk * BW, VT(), dd, vv);  // unit-local ids
+            else
+                load_block(post + blk * BW, VT(), dd, vv);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d[4 * h + c] = (p + c >= head && p + c < span) ? dd[c] : -1;
+                // CP: d = the accumulator index inside the tile (local id - the tile's offset in its unit); a sentinel's
+                // (local id >= 49152) lies outside [0, G) for every tile of a unit and is skipped by add_batch
+                const int dc = CP ? dd[c] - (tile_base - ubase) : dd[c];
+                d[4 * h + c] = (p + c >= head && p + c < span) ? dc : -1;
                 v[4 * h + c] = vv[c];
             }
         }
@@ -282,7 +290,8 @@ __device__ void dense_tile_accumulate(ScoreShared &S, const IndexView &ix, int n
         float *slot[NB];
         float acc_r[NB];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) slot[r] = (d[r] >= 0) ? acc + (d[r] - tile_base) : dummy;
+        for (int r = 0; r < NB; ++r)
+            slot[r] = CP ? (((unsigned)d[r] < (unsigned)G) ? acc + d[r] : dummy) : ((d[r] >= 0) ? acc + (d[r] - tile_base) : dummy);
 #pragma unroll
         for (int r = 0; r < NB; ++r) acc_r[r] = *slot[r];
 #pragma unroll
@@ -346,8 +355,8 @@ constexpr int FLAT_SLOTS = 2048;               // doc hash slots of the grouping
 constexpr int FLAT_MPT = FLAT_MCAP / THREADS;  // 8
 constexpr int FLAT_MIN_TERMS = 12;             // below this the term-by-term paths are at least as good
 
-template <typename VT, bool AFTER>
-__device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_len, int tile_base, int k) {
+template <typename VT, bool AFTER, bool CP>
+__device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_len, int tile_base, int k) {  // one-tile units: the tile IS the unit
     const int tid = threadIdx.x;
     unsigned *bm1 = S.tbl, *bm2 = S.tbl + 512;
     int *pre = reinterpret_cast<int *>(S.tbl + 1024);  // [nt + 1] exclusive prefix of m_len: flat posting index -> term
@@ -359,7 +368,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
     int *hk = reinterpret_cast<int *>(S.tbl + 10240);
     int *hcnt = reinterpret_cast<int *>(S.tbl + 12288);
     int *hoff = reinterpret_cast<int *>(S.tbl + 14336);
-    const int32_t *post = ix.post;
+    const int32_t *post = CP ? ix.post16 : ix.post;
 
     unsigned P;
     const unsigned first = block_excl_scan(tid < nt ? (unsigned)my_len : 0u, S.tk.red, &P);
@@ -379,7 +388,7 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
         int i = 0;
         for (int f = tid; f < (int)P; f += THREADS) {
             while (f >= pre[i + 1]) ++i;
-            const int da = post_doc_at<VT>(post, S.m_start[i] + (f - pre[i]));
+            const int da = CP ? post16_doc_at<VT>(post, S.m_start[i] + (f - pre[i]), tile_base) : post_doc_at<VT>(post, S.m_start[i] + (f - pre[i]));
             if (da >= 0) {  // not a sentinel
                 const int d = da - tile_base;
                 const unsigned bit = 1u << (d & 31);
@@ -402,9 +411,9 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
             if (f < (int)P) {
                 while (f >= pre[i + 1]) ++i;
                 const int64_t g = S.m_start[i] + (f - pre[i]);
-                const int da = post_doc_at<VT>(post, g);
+                const int da = CP ? post16_doc_at<VT>(post, g, tile_base) : post_doc_at<VT>(post, g);
                 const int d = da - tile_base;
-                const float c = (post_val_at(post, g, VT()) * S.m_idf[i]) * S.m_qw[i];
+                const float c = ((CP ? post16_val_at(post, g, VT()) : post_val_at(post, g, VT())) * S.m_idf[i]) * S.m_qw[i];
                 if (da < 0) {  // sentinel: nothing
                 } else if ((bm2[d >> 5] >> (d & 31)) & 1u) {
                     const unsigned e = atomicAdd(mcount, 1u);
@@ -525,16 +534,17 @@ __device__ bool flat_tile(ScoreShared &S, const IndexView &ix, int nt, int my_le
 // (Measured and dropped: reading the compact copy of srx_common.h here on one-tile units -- a local id IS the accumulator
 // index, one 16-byte load per fp16 block instead of 16 + 8.  C4: 21.7 -> 20.8 ms per batch for 33 % fewer bytes: the path
 // is bound by its LDS round trips, not by HBM, so the second copy's traffic saving buys little.)
-template <typename VT, bool ALIGNED>
+template <typename VT, bool ALIGNED, bool CP>
 __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int nt, int64_t tile_base, bool has_tile, int64_t wstart,
                                       int wlen, float my_idf, float my_qw) {
-    constexpr int BW = BlockWords<VT>::value;
+    constexpr int BW = CP ? CompactWords<VT>::value : BlockWords<VT>::value;
+    const int ubase = (int)((((tile_base >> ix.tile_log2) / ix.unit_tiles) * ix.unit_tiles) << ix.tile_log2);  // first doc of the tile's build unit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = 1 << ix.tile_log2;
     float *acc = reinterpret_cast<float *>(S.tbl) + wave * G;
     for (int i = lane; i < G / 4; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!has_tile) return;  // uniform per wave
-    const int32_t *post = ix.post;
+    const int32_t *post = CP ? ix.post16 : ix.post;
     const int64_t idle_blk = ix.zero_block + lane;  // my all-sentinel block
     // iterator over (term, step): 64 blocks per step
     int it = 0, istep = 0;       // next (term, step) to load
@@ -571,12 +581,18 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
         const bool ok = valid && bi < cnb;
         int dd[4];
         float vv[4];
-        load_block(post + (ok ? (cs >> 2) + bi : idle_blk) * BW, VT(), dd, vv);
+        if constexpr (CP)
+            load_block16(post + (ok ? (cs >> 2) + bi : idle_blk) * BW, VT(), dd, vv);  // unit-local ids; a sentinel's (>= 49152) is no
+        else                                                                           // accumulator index of any tile
+            load_block(post + (ok ? (cs >> 2) + bi : idle_blk) * BW, VT(), dd, vv);
         const int head = (int)(cs & 3), span = head + cl;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int p = bi * 4 + c;
-            b.d[c] = (ALIGNED || (ok && p >= head && p < span)) ? dd[c] : -1;
+            // CP: b.d = the accumulator index inside the tile (local id - the tile's offset in its unit: 0 on one-tile units);
+            // anything outside [0, G) is skipped by add()
+            const int dc = CP ? dd[c] - (int)(tile_base - ubase) : dd[c];
+            b.d[c] = (ALIGNED || (ok && p >= head && p < span)) ? dc : -1;
             b.v[c] = vv[c];
         }
         if (valid) ++istep;
@@ -588,7 +604,8 @@ __device__ void wave_dense_accumulate(ScoreShared &S, const IndexView &ix, int n
         float *slot[4];
         float a[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) slot[c] = (b.d[c] >= 0) ? acc0 + b.d[c] : dummy;
+        for (int c = 0; c < 4; ++c)
+            slot[c] = CP ? (((unsigned)b.d[c] < (unsigned)G) ? acc + b.d[c] : dummy) : ((b.d[c] >= 0) ? acc0 + b.d[c] : dummy);
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c] = *slot[c];
 #pragma unroll
@@ -928,7 +945,7 @@ __device__ void dense_tile_select(ScoreShared &S, const IndexView &ix, int tile_
 #endif
 constexpr int DENSE_MIN = SRX_DENSE_MIN < HASH_CAP ? SRX_DENSE_MIN : HASH_CAP;  // a tile with more postings than this is accumulated densely
 
-template <typename VT, bool AFTER>
+template <typename VT, bool AFTER, bool CP>
 __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const int32_t *__restrict__ q_ptr,
                             const int32_t *__restrict__ q_term, const float *__restrict__ q_weight, int nq, int k,
                             int n_splits, int n_whole, int tpu, int n_super, int dbg, const unsigned *__restrict__ ovf,
@@ -1039,9 +1056,9 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 b_n = gload_i32(wskip + min(j + WAVES, jlast) + 1);
                 T2(0);
                 if (wd_aligned)
-                    wave_dense_accumulate<VT, true>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
+                    wave_dense_accumulate<VT, true, CP>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
                 else
-                    wave_dense_accumulate<VT, false>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
+                    wave_dense_accumulate<VT, false, CP>(S, ix, nt, (int64_t)j << ix.tile_log2, has_tile, wbase + a, b - a, w_idf, w_qw);
                 const int n_old = (int)S.tk.count;  // stable here: nothing appends before the barrier
                 __syncthreads();
                 T2(3); T2C(11);
@@ -1077,7 +1094,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 }
                 __syncthreads();
                 T2(0);
-                served = flat_tile<VT, AFTER>(S, ix, nt, my_len, su << ix.tile_log2, k);
+                served = flat_tile<VT, AFTER, CP>(S, ix, nt, my_len, su << ix.tile_log2, k);
                 T2(1); T2C(9);
                 for (int i = tid; i < SLOTS; i += THREADS) keys[i] = EMPTY_KEY;  // back to hash mode
                 __syncthreads();
@@ -1090,7 +1107,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                 }
                 __syncthreads();
                 T2(0);
-                hash_unit<VT, AFTER>(S, ix, nt, my_len, k, dbg);
+                hash_unit<VT, AFTER, CP>(S, ix, nt, my_len, k, (su * tps) << ix.tile_log2, dbg);
                 T2(2); T2C(10);
             } else if (P > 0 && wave_dense) {
                 dense_quads(su * tps, min(su * tps + tps, ix.n_tiles));
@@ -1145,12 +1162,12 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     __syncthreads();
                     if (GP <= (unsigned)DENSE_MIN) {
                         T2(0);
-                        hash_unit<VT, AFTER>(S, ix, nt, glen, k, dbg);
+                        hash_unit<VT, AFTER, CP>(S, ix, nt, glen, k, (su * tps) << ix.tile_log2, dbg);
                         T2(2); T2C(10);
                     } else {  // one dense tile (gb == ga + 1 by construction)
                         const int tile_base = ga << ix.tile_log2;
                         T2(0);
-                        dense_tile_accumulate<VT>(S, ix, nt, tile_base, true);
+                        dense_tile_accumulate<VT, CP>(S, ix, nt, tile_base, true, (su * tps) << ix.tile_log2);
                         T2(3); T2C(11);
                         dense_tile_select<AFTER>(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);  // m_start / m_len are live: no overflow area
                         T2(4);
@@ -1181,7 +1198,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
                     S.m_qw[tid] = q_weight[t0 + pass * MAXT + tid];
                 }
                 __syncthreads();
-                dense_tile_accumulate<VT>(S, ix, nt, tile_base, pass == 0);
+                dense_tile_accumulate<VT, CP>(S, ix, nt, tile_base, pass == 0, ((j / ix.unit_tiles) * ix.unit_tiles) << ix.tile_log2);
             }
             dense_tile_select<AFTER>(S, ix, tile_base, k, 1, (dbg & 8192) ? -1 : n_old, 0);
         }
@@ -1227,7 +1244,7 @@ __device__ void score_block(ScoreShared &S, int bid, const IndexView &ix, const 
 
 // Tier-2 kernel: a fixed grid of workgroups drains the worklist of (query, split) blocks that tier 1 could not
 // finish (flagged units, > 64 terms, k > 128).  work[0] = number of entries, work[1..] = block ids.
-template <typename VT, bool AFTER>
+template <typename VT, bool AFTER, bool CP>
 __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, const int32_t *__restrict__ q_ptr,
                                                                const int32_t *__restrict__ q_term,
                                                                const float *__restrict__ q_weight, int nq, int k,
@@ -1245,7 +1262,7 @@ __global__ __launch_bounds__(THREADS, 2) void srx_score_kernel(IndexView ix, con
     if (fin.hint != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fin.hint = n_work;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // the previous block's LDS state is dead
-        score_block<VT, AFTER>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
+        score_block<VT, AFTER, CP>(S, work[1 + w], ix, q_ptr, q_term, q_weight, nq, k, n_splits, n_whole, tpu, n_super, dbg, ovf,
                         ovf_words, lists_per_q, cand_doc, cand_score, cand_count, after_doc, after_score, doc_base, fin);
     }
 }
@@ -1566,8 +1583,10 @@ SRX_API int srx_index_create(const srx_index_desc *d, srx_index **out) {
     if (d->val_type != SRX_VAL_F32 && d->val_type != SRX_VAL_F16) return fail(SRX_ERR_INVALID, "srx_index_create: bad val_type%s");
     if (d->unit_tiles < 1 || d->unit_tiles > MAX_TPS) return fail(SRX_ERR_INVALID, "srx_index_create: unit_tiles must be in [1, 64]%s");
     if (d->n_blocks < 0 || d->n_blocks * 4 < d->nnz) return fail(SRX_ERR_INVALID, "srx_index_create: n_blocks does not cover nnz%s");
-    if (!d->term_ptr || !d->tile_skip || !d->idf || !d->post)
+    if (!d->term_ptr || !d->tile_skip || !d->idf || (!d->post && !d->post16))
         return fail(SRX_ERR_INVALID, "srx_index_create: null index array%s");
+    if (!d->post && ((int64_t)d->unit_tiles << d->tile_log2) > W_UNIT_MAX_DOCS)
+        return fail(SRX_ERR_INVALID, "srx_index_create: an index without canonical blocks needs units of <= 49152 docs (the compact copy)%s");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (d->device < 0 || d->device >= ndev) return fail(SRX_ERR_NODEVICE, "srx_index_create: device ordinal not visible%s");
@@ -1692,6 +1711,8 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ix->d.device));
     const Plan p = make_plan(ix, nq, k);
+    if (ix->d.post == nullptr && p.tpu != ix->d.unit_tiles)
+        return fail(SRX_ERR_INVALID, "srx_search: this index keeps no canonical blocks: a unit other than the one it was built for cannot be served%s");
     const int64_t lists = (int64_t)nq * p.lists_per_q;
     const int64_t blocks = (int64_t)p.n_whole + (int64_t)(nq - p.n_whole) * p.n_splits;
     if (lists > 0x7FFFFFFFll) return fail(SRX_ERR_INVALID, "srx_search: nq * splits overflows the grid%s");
@@ -1756,14 +1777,17 @@ int search_impl(srx_index *ix, const int32_t *q_ptr, const int32_t *q_term, cons
     const unsigned t2_grid = (unsigned)((hint == 0 && !t2_everything && t2_full > 128) ? 128 : t2_full);
     Tier2Final fin;
     fin.out_doc = out_doc; fin.out_score = out_score; fin.out_count = out_count; fin.ors = ors; fin.ocs = ocs; fin.hint = ix->d_hint;
-#define SRX_LAUNCH_T2(VT, AFTER)                                                                                                  \
-    hipLaunchKernelGGL((srx_score_kernel<VT, AFTER>), dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term, q_weight, nq, k,   \
-                       p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q, work, cand_doc, cand_score, \
+#define SRX_LAUNCH_T2(VT, AFTER, CP)                                                                                                \
+    hipLaunchKernelGGL((srx_score_kernel<VT, AFTER, CP>), dim3(t2_grid), dim3(THREADS), 0, stream, v, q_ptr, q_term, q_weight, nq, k, \
+                       p.n_splits, p.n_whole, p.tpu, p.n_super, dbg2, ovf, p.ovf_words, p.lists_per_q, work, cand_doc, cand_score,   \
                        cand_count, after_doc, after_score, ix->d.doc_base, fin)
+    const bool cp = ix->d.post == nullptr;  // no canonical blocks: tier 2 reads the compact copy too
     if (ix->d.val_type == SRX_VAL_F32) {
-        if (after_score) SRX_LAUNCH_T2(float, true); else SRX_LAUNCH_T2(float, false);
+        if (after_score) { if (cp) SRX_LAUNCH_T2(float, true, true); else SRX_LAUNCH_T2(float, true, false); }
+        else { if (cp) SRX_LAUNCH_T2(float, false, true); else SRX_LAUNCH_T2(float, false, false); }
     } else {
-        if (after_score) SRX_LAUNCH_T2(__half, true); else SRX_LAUNCH_T2(__half, false);
+        if (after_score) { if (cp) SRX_LAUNCH_T2(__half, true, true); else SRX_LAUNCH_T2(__half, true, false); }
+        else { if (cp) SRX_LAUNCH_T2(__half, false, true); else SRX_LAUNCH_T2(__half, false, false); }
     }
 #undef SRX_LAUNCH_T2
     HIP_TRY(hipGetLastError());

@@ -492,6 +492,21 @@ __device__ __forceinline__ void load_block16(const int32_t *blk, __half, int (&d
     v[0] = __low2float(h0); v[1] = __high2float(h0); v[2] = __low2float(h1); v[3] = __high2float(h1);
 }
 
+// Tier 2 on the compact copy (an index that dropped its canonical blocks): the same accessors with the unit's first doc
+// added to the 16-bit local id; a sentinel (local id >= W_SENT_BASE) reads as doc -1 like a canonical one.
+template <typename VT>
+__device__ __forceinline__ int post16_doc_at(const int32_t *p16, int64_t p, int ubase) {
+    const unsigned w = (unsigned)gload_i32(p16 + (p >> 2) * CompactWords<VT>::value + ((p & 3) >> 1));
+    const unsigned l = (p & 1) ? (w >> 16) : (w & 0xFFFFu);
+    return l >= (unsigned)W_SENT_BASE ? -1 : ubase + (int)l;
+}
+__device__ __forceinline__ float post16_val_at(const int32_t *p16, int64_t p, float) {
+    return __int_as_float(gload_i32(p16 + (p >> 2) * 6 + 2 + (p & 3)));
+}
+__device__ __forceinline__ float post16_val_at(const int32_t *p16, int64_t p, __half) {
+    const unsigned w = (unsigned)gload_i32(p16 + (p >> 2) * 4 + 2 + ((p & 3) >> 1));
+    return __half2float(__ushort_as_half((unsigned short)((p & 1) ? (w >> 16) : (w & 0xFFFFu))));
+}
 // the same block with the two id words left packed (tier 1 keeps them that way in registers)
 __device__ __forceinline__ void load_block16p(const int32_t *blk, float, unsigned (&d)[2], float (&v)[4]) {
     const srx_i2u a = gload_i2(blk);

@@ -179,7 +179,7 @@ class DeviceIndex:
     keeps pointers."""
 
     def __init__(self, term_ptr, post, tile_skip, idf, n_docs: int, vocab: int, doc_base: int, tile_log2: int, device, *,
-                 nnz: int, n_blocks: int, unit_tiles: int, val_type: int, term_bound=None, fine_bound=None):
+                 nnz: int, n_blocks: int, unit_tiles: int, val_type: int, term_bound=None, fine_bound=None, keep_canonical: bool = True):
         torch = _torch()
         self.device = torch.device(device)
         self.term_ptr, self.post, self.tile_skip, self.idf = term_ptr, post, tile_skip, idf
@@ -196,6 +196,8 @@ class DeviceIndex:
         self._create_handle(term_bound)
         self._ws = None
         self._opts = _capi.SearchOpts()
+        if not keep_canonical:
+            self.drop_canonical()
 
     @property
     def value_bytes(self) -> int:
@@ -218,6 +220,21 @@ class DeviceIndex:
                                                       self.unit_tiles, _ptr(out), _stream_ptr(torch, self.device)), "srx_build_compact")
             torch.cuda.current_stream(self.device).synchronize()
         return out
+
+    def drop_canonical(self) -> bool:
+        """Keep ONE copy of the postings: free the canonical blocks (8 / 6 bytes per posting) and let the tier-2 kernel read
+        the compact copy (6 / 4 bytes) tier 1 streams -- 57 % of the posting memory on fp32 values, and fewer bytes for tier 2
+        to move.  Possible when the compact copy exists (units of <= 49 152 docs).  Afterwards the index cannot be saved to a
+        shard file (that format stores the canonical blocks) and cannot be searched with another unit than the one it was
+        built for (``set_opts(supertile_log2 / unit_tiles)``).  Returns whether the copy was dropped."""
+        torch = _torch()
+        if self.post16 is None or self.post is None:
+            return False
+        torch.cuda.synchronize(self.device)
+        self.post = None
+        self._create_handle(self.term_bound)
+        _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
+        return True
 
     def _create_handle(self, table) -> None:
         d = _capi.IndexDesc(device=self.device.index or 0, val_type=self.val_type, n_docs=self.n_docs, vocab=self.vocab,
@@ -248,8 +265,9 @@ class DeviceIndex:
     @classmethod
     def from_csr(cls, indptr, indices, data, idf, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0) -> "DeviceIndex":
-        """Build from a doc-major CSR (host numpy or device torch arrays).
+                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0, keep_canonical: bool = True) -> "DeviceIndex":
+        """Build from a doc-major CSR (host numpy or device torch arrays).  ``keep_canonical=False``: one resident copy of the
+        postings (see :meth:`drop_canonical`).
 
         mode "bm25": post_val = impact(tf, len) precomputed in fp32 (retrieval.py:58,70-71), idf as given.
         mode "dot" : post_val = data (optionally fp16), contribution data*idf*qw (evaluate_rag_pipeline.py:117).
@@ -275,12 +293,12 @@ class DeviceIndex:
             dl = None if doc_lengths is None else to_dev(doc_lengths, torch.float32)
             return cls.from_coo(rows, cols, vals, to_dev(idf, torch.float32), n_docs, doc_lengths=dl, k1=k1, b=b,
                                 avgdl=avgdl, mode=mode, val_dtype=val_dtype, device=dev, doc_base=doc_base,
-                                tile_log2=tile_log2, score_bounds=score_bounds, unit_tiles=unit_tiles)
+                                tile_log2=tile_log2, score_bounds=score_bounds, unit_tiles=unit_tiles, keep_canonical=keep_canonical)
 
     @classmethod
     def from_coo(cls, rows, cols, vals, idf, n_docs: int, *, doc_lengths=None, k1: float = 1.2, b: float = 0.75,
                  avgdl: float = 1.0, mode: str = "bm25", val_dtype: str = "f32", device="cuda:0", doc_base: int = 0,
-                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0) -> "DeviceIndex":
+                 tile_log2: int = 14, score_bounds: bool = True, unit_tiles: int = 0, keep_canonical: bool = True) -> "DeviceIndex":
         """Build from device COO triples sorted by (row, col) -- i.e. the CSR's nnz order with explicit rows
         (rows i32 shard-local, cols i32, vals f32).  CSR -> CSC is one stable sort by term, which keeps rows
         ascending inside a term; the term-major arrays are then scattered into the blocked layout of
@@ -370,7 +388,7 @@ class DeviceIndex:
             torch.cuda.synchronize(dev)
             del cols_sorted, skip, runpad, post_doc, post_val
         return cls(term_ptr_pad, post, tile_skip, idf_d, n_docs, V, doc_base, tile_log2, dev, nnz=nnz, n_blocks=n_blocks,
-                   unit_tiles=unit_tiles, val_type=val_type, term_bound=term_bound, fine_bound=fine_bound)
+                   unit_tiles=unit_tiles, val_type=val_type, term_bound=term_bound, fine_bound=fine_bound, keep_canonical=keep_canonical)
 
     BOUND_KS = (1, 10, 100, 1000)  # the ranks K the engine looks up (include/sparse_rx.h: term_bound[vocab*4])
     FINE_KS = (1, 2, 4, 8, 10, 16, 32, 64, 100, 128, 256, 512, 1000, 1024)  # ... and the ranks kept for combining shards
@@ -407,6 +425,8 @@ class DeviceIndex:
         """Write this shard (blocked postings, skip table, idf, bounds) to a native shard file (shardfile.py)."""
         from . import shardfile
         torch = _torch()
+        if self.post is None:
+            raise ValueError("this index dropped its canonical blocks (drop_canonical): the shard file stores them -- save before dropping")
         torch.cuda.synchronize(self.device)
         arrays = {n: getattr(self, n).cpu().numpy() for n in ("term_ptr", "post", "tile_skip", "idf")}
         if self.term_bound is not None:
@@ -419,7 +439,8 @@ class DeviceIndex:
                                                   "val_type": self.val_type, "block_pad": BLOCK_PAD})
 
     @classmethod
-    def load(cls, path: str, device="cuda:0", doc_base=None, verify: bool = True, chunk_bytes: int = 1 << 28) -> "DeviceIndex":
+    def load(cls, path: str, device="cuda:0", doc_base=None, verify: bool = True, chunk_bytes: int = 1 << 28,
+             keep_canonical: bool = True) -> "DeviceIndex":
         """Read a native shard file: memory-map it, validate it (shardfile.read_shard_file) and stream every array to
         the GPU in chunks."""
         from . import shardfile
@@ -444,12 +465,14 @@ class DeviceIndex:
             return cls(up(arr["term_ptr"]), up(arr["post"]), up(arr["tile_skip"]), up(arr["idf"]), int(meta["n_docs"]),
                        int(meta["vocab"]), int(meta["doc_base"] if doc_base is None else doc_base), int(meta["tile_log2"]), dev,
                        nnz=int(meta["nnz"]), n_blocks=int(meta["n_blocks"]), unit_tiles=int(meta["unit_tiles"]),
-                       val_type=int(meta["val_type"]), term_bound=tb, fine_bound=fb)
+                       val_type=int(meta["val_type"]), term_bound=tb, fine_bound=fb, keep_canonical=keep_canonical)
 
     # -- search ----------------------------------------------------------------------------------------
     def set_opts(self, supertile_log2: int = 0, target_blocks: int = 0, profile: int = 0, debug: int = 0,
                  unit_tiles: int = 0) -> None:
         """profile = N > 0: every N-th search is bracketed with hipEvents (True = every search)."""
+        if self.post is None and (supertile_log2 or unit_tiles):
+            raise ValueError("this index keeps no canonical blocks (drop_canonical): it is searched with the unit it was built for")
         self._opts = _capi.SearchOpts(supertile_log2=supertile_log2, target_blocks=target_blocks, profile=int(profile),
                                       reserved=int(debug), unit_tiles=int(unit_tiles))
         _capi.check(_capi.lib().srx_index_set_opts(self._h, ctypes.byref(self._opts)), "srx_index_set_opts")
@@ -552,7 +575,7 @@ class DeviceIndex:
     def device_bytes(self) -> int:
         """Everything this shard keeps resident: both copies of the postings (canonical 8 / 6 bytes per posting + the
         compact tier-1 copy 6 / 4), the skip table, idf and the bound tables."""
-        ts = [self.term_ptr, self.post, self.post16, self.tile_skip, self.idf, self.term_bound, self.fine_bound]
+        ts = [self.term_ptr, self.post, self.post16, self.tile_skip, self.idf, self.term_bound, self.fine_bound]  # post is None after drop_canonical
         return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
     def close(self) -> None:

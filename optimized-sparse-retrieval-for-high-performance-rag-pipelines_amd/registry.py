@@ -34,10 +34,10 @@ class _SparseRetrieverBase:
     term_order = "term"  # accumulation order of a doc's contributions (index.encode_queries)
 
     def __init__(self, k1: float, b: float, device: Optional[str], tile_log2: int, use_cache: bool = True, group=None,
-                 shard_searcher_factory=None, sharded: Optional[bool] = None):
+                 shard_searcher_factory=None, sharded: Optional[bool] = None, one_copy: bool = True):
         self.k1, self.b = k1, b
         # one GPU, or -- inside an initialised torch.distributed group -- doc-range shards (backend.SparseBackend)
-        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded)
+        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded, one_copy=one_copy)
         self.device, self.tile_log2 = self._be.device, tile_log2
         self.query_cache: Optional[Dict[str, Tuple[np.ndarray, np.ndarray]]] = {} if use_cache else None
         self.cache_lock = threading.RLock()
@@ -128,7 +128,8 @@ class OptimizedBM25Retriever(_SparseRetrieverBase):
     def __init__(self, method: str = "bm25", model: str = None, k1: float = 1.2, b: float = 0.75, device: Optional[str] = None,
                  tile_log2: int = 14, **kwargs):
         super().__init__(k1, b, device, tile_log2, use_cache=kwargs.get("cache_queries", True), group=kwargs.get("group"),
-                         shard_searcher_factory=kwargs.get("shard_searcher_factory"), sharded=kwargs.get("sharded"))
+                         shard_searcher_factory=kwargs.get("shard_searcher_factory"), sharded=kwargs.get("sharded"),
+                         one_copy=kwargs.get("one_copy", True))
         self.method = method.lower()
         self.model_name = model
         self.use_simd = kwargs.get("use_simd", True)  # accepted, meaningless here
@@ -154,7 +155,7 @@ class OptimizedRetriever(_SparseRetrieverBase):
 
     def __init__(self, config: Dict[str, Any], hardware_info: Optional[Dict[str, Any]] = None, device: Optional[str] = None,
                  tile_log2: int = 14, cache_dir: str = ".rag_cache", accumulation: str = "token", group=None,
-                 shard_searcher_factory=None, sharded: Optional[bool] = None):
+                 shard_searcher_factory=None, sharded: Optional[bool] = None, one_copy: bool = True):
         if accumulation not in ("token", "term"):
             raise ValueError("accumulation must be 'token' or 'term'")
         self.term_order = accumulation
@@ -162,7 +163,7 @@ class OptimizedRetriever(_SparseRetrieverBase):
         hardware_info = hardware_info or {"memory_gb": 8, "cores": 4}
         super().__init__(params.get("k1", 1.2), params.get("b", 0.75), device, tile_log2,
                          use_cache=hardware_info.get("memory_gb", 8) > 4, group=group, shard_searcher_factory=shard_searcher_factory,
-                         sharded=sharded)
+                         sharded=sharded, one_copy=one_copy)
         self.config, self.hardware = config, hardware_info
         self.method = config.get("type", "bm25").lower()
         self.mode = "bm25" if self.method in ("bm25", "bm25_custom") else "dot"  # :258-261, :378-399

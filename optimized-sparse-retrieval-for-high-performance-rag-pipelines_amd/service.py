@@ -44,7 +44,7 @@ class RetrievalService:
 
     def __init__(self, index_path=None, embedding_path=None, num_workers: int = 4, cache_size: int = 1000, *,
                  device: Optional[str] = None, tile_log2: int = 14, group=None, sharded: Optional[bool] = None,
-                 shard_searcher_factory=None, **compat_kwargs):
+                 shard_searcher_factory=None, one_copy: bool = True, **compat_kwargs):
         # index_path / embedding_path / num_workers are accepted for signature compatibility (retrieval.py:98-102);
         # README-only kwargs (use_simd, batch_size, monitor, ...) are swallowed.
         self.index_path = index_path
@@ -55,7 +55,8 @@ class RetrievalService:
         # group: the torch.distributed group to shard over (None = the default group, when one is initialised);
         # shard_searcher_factory: test hook of backend.SparseBackend (the product never sets it)
         # sharded: None = automatic (a group of more than one rank), True = the sharded path even in a group of one rank
-        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded)
+        # one_copy: only the compact copy of the postings stays in HBM (backend.SparseBackend)
+        self._be = SparseBackend(device, tile_log2, group=group, searcher_factory=shard_searcher_factory, sharded=sharded, one_copy=one_copy)
         self.device = self._be.device
         self.tile_log2 = tile_log2
         self.k1: float = 1.2   # retrieval.py:116

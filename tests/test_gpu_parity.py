@@ -546,7 +546,8 @@ def test_c4_full_size(rx):
     k = 1000 by tier 2 from the canonical blocks), a sub-batch under another work-item plan, the block-level dense tiles."""
     from sparse_rx import synth
     n_docs, V, nq, k = 5_000_000, 30_000, 1_000, 1000
-    ix, idf, avgdl, host = _full_size_index(rx, "splade", n_docs, V, 150, 20254, True, tile_log2=12, unit_tiles=1)
+    ix, idf, avgdl, host = _full_size_index(rx, "splade", n_docs, V, 150, 20254, True, tile_log2=12, unit_tiles=1, keep_canonical=False)
+    assert ix.post is None  # one copy of the postings, as bench.py runs it: tier 2 reads the compact blocks
     q = synth.queries_np(nq, V, 50, seed=20255, dist="zipf", s=0.7, weights="learned")
     got = ix.search(*q, k)
     d, s, n = got
@@ -573,7 +574,8 @@ def test_c5_full_size(rx):
     idempotence, k-prefix, a sub-batch under another plan, and the tier-2 kernel alone against the default two-tier plan."""
     from sparse_rx import synth
     n_docs, V, nq, k = 10_000_000, 100_000, 256, 100
-    ix, idf, avgdl, host = _full_size_index(rx, "zipf", n_docs, V, 100, 20255, True, tile_log2=14)
+    ix, idf, avgdl, host = _full_size_index(rx, "zipf", n_docs, V, 100, 20255, True, tile_log2=14, keep_canonical=False)
+    assert ix.post is None
     q = synth.queries_np(nq, V, 8, seed=20256, dist="zipf", s=1.0)
     got = ix.search(*q, k)
     d, s, n = got
@@ -593,6 +595,74 @@ def test_c5_full_size(rx):
     ix.set_opts(debug=8)  # everything through the tier-2 kernel
     _assert_rows_equal(ix.search(*q, k), got, "c5 tier 2 alone")
     ix.close()
+
+
+def test_one_copy_of_the_postings(rx, tmp_path):
+    """``keep_canonical=False`` / ``drop_canonical()``: the canonical blocks are freed and the tier-2 kernel reads the compact
+    copy (16-bit unit-local ids + the unit's first doc).  Every tier-2 path -- hash units, flat tiles, block- and
+    wave-level dense tiles (masked / unmasked), the overflow packer, > 256-term queries, search-after pages -- must return
+    the oracle's rows bit for bit, alone (debug = 8) and behind tier 1; what needs the canonical blocks raises."""
+    from sparse_rx import synth
+    cz = synth.zipf_corpus_np(120_000, 5_000, 60, seed=20255)   # hot terms: dense tiles, packer, negative idf
+    _, idf, avgdl = synth.corpus_stats(cz)
+    qz = synth.queries_np(64, cz.vocab, 8, seed=5, dist="zipf")
+    for kw in (dict(tile_log2=14), dict(tile_log2=10), dict(tile_log2=12, unit_tiles=1), dict(tile_log2=12, unit_tiles=2)):
+        both = _dev_index(rx, cz, idf, avgdl, **kw)
+        one = _dev_index(rx, cz, idf, avgdl, keep_canonical=False, **kw)
+        assert one.post is None and one.post16 is not None and one.device_bytes() < 0.6 * both.device_bytes()
+        for dbg in (0, 8):
+            one.set_opts(debug=dbg)
+            for k in (100, 1000, 1, 2500):
+                _assert_exact(one.search(*qz, k), _oracle_batch(cz, idf, avgdl, qz, k), f"one copy zipf {kw} dbg={dbg} k={k}")
+        with pytest.raises(ValueError, match="canonical"):
+            one.set_opts(supertile_log2=16)
+        with pytest.raises(ValueError, match="canonical"):
+            one.save(str(tmp_path / "x.srx"))
+        assert both.drop_canonical() and both.post is None and not both.drop_canonical()
+        _assert_exact(both.search(*qz, 100), _oracle_batch(cz, idf, avgdl, qz, 100), f"dropped later {kw}")
+        both.close()
+        one.close()
+    cs = synth.splade_corpus_np(60_000, 3_000, 100, seed=20254)  # 50-term queries, fp16, k = 1000: flat tiles + wave-level dense tiles
+    ones = np.ones(cs.vocab, dtype=np.float32)
+    qs = synth.queries_np(32, cs.vocab, 50, seed=9, dist="zipf", s=0.7, weights="learned")
+    exp = _oracle_batch(cs, ones, 1.0, qs, 1000, mode=oracle.MODE_TFIDF_F32)
+    for vd, tl, ut in (("f16", 13, 0), ("f32", 13, 0), ("f16", 12, 1), ("f32", 12, 1), ("f16", 12, 4), ("f16", 10, 1), ("f32", 11, 3)):
+        ix = rx.DeviceIndex.from_csr(cs.indptr, cs.indices, cs.data, ones, mode="dot", val_dtype=vd, tile_log2=tl, unit_tiles=ut, keep_canonical=False)
+        assert ix.post is None
+        _assert_exact(ix.search(*qs, 1000), exp, f"one copy splade {vd} tile={tl} ut={ut}")
+        if tl == 12:
+            for dbg in (2048, 4096, 8192, 128):
+                ix.set_opts(debug=dbg)
+                _assert_exact(ix.search(*qs, 1000), exp, f"one copy splade {vd} tile={tl} ut={ut} debug={dbg}")
+        ix.close()
+    ce = synth.zipf_corpus_np(5_000, 700, 30, seed=3)            # a > 256-term query: the general path
+    _, idfe, avgdle = synth.corpus_stats(ce)
+    ix = _dev_index(rx, ce, idfe, avgdle, tile_log2=8, keep_canonical=False)
+    long_terms = np.arange(0, 700, 2, dtype=np.int32)
+    qe = (np.array([0, len(long_terms), len(long_terms) + 3], np.int32), np.concatenate([long_terms, np.array([1, 5, 9], np.int32)]),
+          np.ones(len(long_terms) + 3, np.float32))
+    for k in (7, 100, 1024):
+        _assert_exact(ix.search(*qe, k), _oracle_batch(ce, idfe, avgdle, qe, k), f"one copy general path k={k}")
+    ix.close()
+    # the API mirror: RetrievalService(one_copy=True) returns the reference's dicts from half the index memory
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(golden, "text_small.json"), encoding="utf-8") as f:
+        j = json.load(f)
+    sizes = {}
+    for one_copy in (False, True):
+        svc = rx.RetrievalService(device="cuda:0", tile_log2=6, one_copy=one_copy)
+        svc.build_bm25_index(j["corpus"])
+        assert (svc.dev.post is None) == one_copy
+        sizes[one_copy] = svc.get_stats()["device_index_mb"]
+        row = {d: i for i, d in enumerate(svc.doc_ids)}
+        for kk in ("3", "10", "1000"):
+            got = svc.search_bm25(j["queries"], top_k=int(kk))
+            for qid, e in j["results"][kk].items():
+                g = got[qid]
+                assert_ranked_equal([row[d] for d in g], np.array(list(g.values()), np.float32), [row[d] for d in e],
+                                    np.array(list(e.values()), np.float32), k=min(int(kk), len(row)), label=f"one_copy={one_copy} k={kk} {qid}")
+        svc.close()
+    assert sizes[True] < sizes[False]
 
 
 def test_registry_twin_golden(rx, golden_dir, tmp_path):

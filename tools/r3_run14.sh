@@ -1,0 +1,7 @@
+#!/bin/bash
+# Dev helper (GPU box): round-3 run 14 -- one resident copy of the postings (tier 2 on the compact blocks): tests, C3 / C4 / C5 with and without the canonical copy
+cd ${GRAFT_REPO_ROOT:-.}
+o=gpurun_out/r3n; mkdir -p $o
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $o/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $o/pytest.log
+[ $rc -eq 0 ] || exit $rc
+bash tools/abl_libs.sh "libsparse_rx.so" "--workload c4 --steps 10" "--workload c4 --steps 10 --keep-canonical" "--workload c5 --steps 10" "--workload c5 --steps 10 --keep-canonical" "--workload c1" "--workload c1 --keep-canonical" "--no-cpu-baseline" "--no-cpu-baseline --keep-canonical" > $o/abl.log 2>&1; cat $o/abl.log
