@@ -96,7 +96,9 @@ typedef struct {
     int32_t unit_tiles; /* tiles per unit the runs are padded for (1..64) */
     int32_t reserved0;
     const int64_t *term_ptr;  /* [vocab+1] */
-    const int32_t *post;      /* [(n_blocks + SRX_BLOCK_PAD) * words per block] */
+    const int32_t *post;      /* [(n_blocks + SRX_BLOCK_PAD) * words per block]; may be NULL when post16 is given: the tier-2
+                                 kernel then reads the compact copy too (one resident copy of the postings; search options
+                                 that change the unit are refused) */
     const int32_t *tile_skip; /* [vocab*(n_tiles+1)] */
     const float *idf;         /* [vocab] */
     const float *term_bound;  /* optional [vocab*4], may be NULL: the K-th largest stored value of each term in this shard for
