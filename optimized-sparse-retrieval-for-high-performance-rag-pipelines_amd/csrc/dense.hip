@@ -92,13 +92,17 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                                                                        float *__restrict__ buf_score,
                                                                        int *__restrict__ buf_cnt, int *__restrict__ ovf,
                                                                        int *__restrict__ any_ovf) {
-    // DT doc tiles of 32 per wave: with two, every A fragment (query tile) read from L2 feeds two MFMAs; the B
-    // fragments of both tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
+    // DT doc tiles of 32 per wave: with two, every A fragment (query tile) feeds two MFMAs; the B fragments of both
+    // tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
+    // Round 3: the query tile's A fragments (KS KiB) are staged through LDS ONCE PER WORKGROUP -- every wave used to read
+    // them from L2 itself (the whole query matrix per 32 docs: 24.6 GB of L2 traffic per 1 M x 768 x 1 024-query batch,
+    // which is what the kernel's 2.5 ms were) -- double-buffered: the next tile's fragments travel global -> registers
+    // while this tile's MFMAs run, registers -> LDS behind them, one barrier per tile.
     constexpr int DT = KS <= 12 ? 2 : 1;
+    __shared__ v4i ldsA[2][KS * 64];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (32 * DT);
-    if (d0 >= n_docs) return;
-    constexpr int DIM = KS * 32;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (32 * DT);  // may lie past the corpus: the wave then only
+    constexpr int DIM = KS * 32;                                                       // helps staging and takes part in the barriers
     v4i B[DT][KS];
     double ds[DT];
     bool dok[DT];
@@ -113,14 +117,34 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
         }
         ds[t] = dok[t] ? (double)corpus_scale[d] : 0.0;
     }
-    for (int q0 = 0; q0 < nq; q0 += 32) {
+    const int n_qt = (nq + 31) / 32;
+    // global -> LDS without a trip through registers (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's
+    // LDS base + 16 l): wave w copies the 64-fragment rows w, w + 4, ... of the tile; no staging VGPRs (with them the kernel
+    // needed 258 registers and fell to one wave per SIMD)
+    const int wv = threadIdx.x >> 6;
+    auto stage_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int row = 0; row < (KS + WAVES - 1) / WAVES; ++row) {
+            const int s = wv + row * WAVES;
+            if (s < KS)  // uniform per wave
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(apack + ((int64_t)tile * KS + s) * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
+        }
+    };
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int qt = 0; qt < n_qt; ++qt) {
+        const int q0 = qt * 32;
         const int qa = q0 + r;
+        const int cur = qt & 1;
+        if (qt + 1 < n_qt) stage_tile(qt + 1, cur ^ 1);  // uniform; the other buffer was last read one barrier ago
         v16i acc[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const v4i A = apack[((int64_t)(q0 >> 5) * KS + s) * 64 + lane];
+            const v4i A = ldsA[cur][s * 64 + lane];
 #pragma unroll
             for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][s], acc[t], 0, 0, 0);
         }
@@ -177,6 +201,8 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the next tile has landed in LDS
+        __syncthreads();  // the next tile's fragments are in LDS, this tile's buffer is free
     }
 }
 

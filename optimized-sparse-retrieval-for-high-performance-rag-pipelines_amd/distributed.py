@@ -257,17 +257,24 @@ class ShardedSearcher:
             cur = torch.cuda.current_stream(dev)
             lanes = []
             try:
+                import torch.distributed as dist
+                if getattr(self, "_lane_groups", None) is None:
+                    # A communicator of its own per lane: the two lanes' collectives run on different streams with nothing
+                    # ordering them against each other, which one RCCL communicator does not allow.  (Collective call: every
+                    # rank builds its lanes at the same point of the same first search.)
+                    ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(dist.get_world_size()))
+                    self._lane_groups = [dist.new_group(ranks=ranks) for _ in range(2)]
                 for li in range(2):
                     st = torch.cuda.Stream(device=dev)
                     ws = torch.empty(max(int(self.workspace_bytes(q_ptr.shape[0] - 1, k)), 1 << 16), dtype=torch.uint8, device=dev)
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         for _ in range(2):  # eager warm-up on the lane's stream (RCCL channel setup, lazy allocations) before the capture
-                            self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws)
+                            self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws, _group=self._lane_groups[li])
                     st.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=st):
-                        out = self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws)
+                        out = self._search_packed(q_ptr, q_term, q_weight, k, world, _lane=("lane", li), _workspace=ws, _group=self._lane_groups[li])
                     lanes.append((st, g, out, ws))
             except Exception as e:  # pragma: no cover  (stack without graph-capturable collectives)
                 import warnings
@@ -282,7 +289,7 @@ class ShardedSearcher:
             g.replay()
         return out
 
-    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int, after=None, _lane=None, _workspace=None):
+    def _search_packed(self, q_ptr, q_term, q_weight, k: int, world: int, after=None, _lane=None, _workspace=None, _group=None):
         """The exchange of :meth:`_exchange` on packed rows end to end: the local search writes packed rows straight
         into the send buffer, the merge reads the received rows in place and writes packed rows, and the results are
         views of the gathered buffer (doc = rows[:, :k], score = rows[:, k:2k] as f32, count = rows[:, 2k]).
@@ -319,18 +326,20 @@ class ShardedSearcher:
             if ev_prev is not None:
                 main.wait_event(ev_prev)  # the exchange that last used this slot's buffers has finished
 
+        grp = _group if _group is not None else self.group
+
         def exchange(mine, send, recv):
             if self.mode == "allgather":
-                dist.all_gather_into_tensor(recv.view(world * nq, row), mine, group=self.group)
+                dist.all_gather_into_tensor(recv.view(world * nq, row), mine, group=grp)
                 out = torch.empty((nq, row), dtype=torch.int32, device=dev)
                 self.merge_packed_out(recv, k, out)
                 return out
             blk = recv.shape[1]
-            dist.all_to_all_single(recv.view(world * blk, row), send, group=self.group)
+            dist.all_to_all_single(recv.view(world * blk, row), send, group=grp)
             merged = torch.empty((blk, row), dtype=torch.int32, device=dev)
             self.merge_packed_out(recv, k, merged)
             allrows = torch.empty((world * blk, row), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(allrows, merged, group=self.group)
+            dist.all_gather_into_tensor(allrows, merged, group=grp)
             return allrows[:nq]
 
         if self.mode == "allgather":
@@ -394,6 +403,13 @@ class ShardedSearcher:
         self._buf = None
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        for g in getattr(self, "_lane_groups", None) or []:  # the lanes' own communicators
+            try:
+                import torch.distributed as dist
+                dist.destroy_process_group(g)
+            except Exception:  # pragma: no cover
+                pass
+        self._lane_groups = None
 
     def _exchange(self, doc, score, count, k: int, world: int, slot: int):
         """Per-shard top-k -> global top-k.
