@@ -58,7 +58,10 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
         if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
     }
     const double ds = dok ? (double)corpus_scale[d] : 0.0;
-    for (int q0 = 0; q0 < nq; q0 += 32) {
+    // gridDim.y splits the query tiles (the threshold sample is a few hundred workgroups of docs only: the split fills the chip)
+    const int n_qt = (nq + 31) / 32, qt_per = (n_qt + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int q_lo = (int)blockIdx.y * qt_per * 32, q_hi = min(nq, q_lo + qt_per * 32);
+    for (int q0 = q_lo; q0 < q_hi; q0 += 32) {
         const int qa = q0 + r;
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -80,8 +83,27 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 
 // The same GEMM with the top-k filter fused in: instead of writing the score, a lane keeps it only if it can still
 // reach the query's top k (score > 0 and >= tau[q], a valid lower bound of the k-th best score taken from a sample of
-// the corpus) and appends (doc, score) to the query's candidate buffer (one atomicAdd per query row and lane half).
-// A full buffer raises the query's overflow flag (the caller then re-ranks that query through the score matrix).
+// the corpus) and appends (doc, score) to the query's candidate buffer.  A full buffer raises the query's overflow flag
+// (the caller then re-ranks that query through the score matrix).
+//
+// Round 3 (the kernel took 1.8 ms per 1 M x 1 024 batch whatever the row length: it waited for one returning global
+// atomic round trip per 32 x 32 tile at two waves per SIMD, and scaled every one of the 10^9 dot products in fp64):
+//  * the query tile's A fragments (KS KiB) are staged through LDS ONCE PER WORKGROUP, double-buffered, by direct
+//    global -> LDS loads (every wave used to read them from L2 itself); beside them a 32-row table {screen, scale, tau};
+//  * an fp32 screen decides which accumulator rows need the exact arithmetic at all: with a = fl32(acc) * ds (one rounding;
+//    |acc| < 2^24 is exact in fp32), a score can reach tau only if a >= tau / qs * (1 - 2^-23)(1 - 2^-24) -- the exact chain
+//    fl32(fl64(fl64(acc * qs) * ds)) >= tau needs acc * qs * ds >= tau (1 - 2^-24)(1 - 2^-52)^2 -- and the table holds
+//    fl32(fl32(tau / qs) * (1 - 2^-20)), which is below that (rows whose quotient is not a normal positive number, and
+//    qs <= 0, are not screened).  3 fp32 instructions per accumulator register; the fp64 chain runs for the registers in
+//    which some lane passes (about a third of them at the design point) and decides alone;
+//  * survivors go to a per-wave LDS list ((query, doc-in-wave), score: 8 bytes) -- wave ballot + mbcnt, no atomics -- and
+//    the list is flushed to the queries' global buffers (one returning atomicAdd per entry, 64 in flight) when half full
+//    and at the end: one global round trip per few hundred survivors instead of one per tile.
+struct DenseTileTab {
+    float thr[32];  // the screen's bound on fl32(acc) * ds; -inf = not screened, +inf = no such query
+    float qs[32];
+    unsigned tau[32];
+};
 template <int KS>
 __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
@@ -94,34 +116,32 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                                                                        int *__restrict__ any_ovf) {
     // DT doc tiles of 32 per wave: with two, every A fragment (query tile) feeds two MFMAs; the B fragments of both
     // tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
-    // Round 3: the query tile's A fragments (KS KiB) are staged through LDS ONCE PER WORKGROUP -- every wave used to read
-    // them from L2 itself (the whole query matrix per 32 docs: 24.6 GB of L2 traffic per 1 M x 768 x 1 024-query batch,
-    // which is what the kernel's 2.5 ms were) -- double-buffered: the next tile's fragments travel global -> registers
-    // while this tile's MFMAs run, registers -> LDS behind them, one barrier per tile.
     constexpr int DT = KS <= 12 ? 2 : 1;
+    constexpr int DENSE_CB = KS > 24 ? 256 : 512;  // per-wave survivor list entries (two workgroups per CU must fit the LDS)
     __shared__ v4i ldsA[2][KS * 64];
+    __shared__ DenseTileTab tab[2];
+    __shared__ uint2 cb[WAVES][DENSE_CB];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (32 * DT);  // may lie past the corpus: the wave then only
-    constexpr int DIM = KS * 32;                                                       // helps staging and takes part in the barriers
+    const int wv = threadIdx.x >> 6;
+    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + wv) * (32 * DT);  // may lie past the corpus: the wave then only helps
+    constexpr int DIM = KS * 32;                                          // staging and takes part in the barriers
     v4i B[DT][KS];
-    double ds[DT];
-    bool dok[DT];
+    float dsf[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
         const int64_t d = d0 + 32 * t + r;
-        dok[t] = d < n_docs;
+        const bool dok = d < n_docs;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             B[t][s] = (v4i){0, 0, 0, 0};
-            if (dok[t]) B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+            if (dok) B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
         }
-        ds[t] = dok[t] ? (double)corpus_scale[d] : 0.0;
+        dsf[t] = dok ? corpus_scale[d] : 0.0f;  // 0: every score of a row past the corpus is 0 or NaN, never > 0
     }
     const int n_qt = (nq + 31) / 32;
     // global -> LDS without a trip through registers (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's
     // LDS base + 16 l): wave w copies the 64-fragment rows w, w + 4, ... of the tile; no staging VGPRs (with them the kernel
     // needed 258 registers and fell to one wave per SIMD)
-    const int wv = threadIdx.x >> 6;
     auto stage_tile = [&](int tile, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int row = 0; row < (KS + WAVES - 1) / WAVES; ++row) {
@@ -131,14 +151,60 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                                                  (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
         }
     };
+    // the tile's table row of query tile * 32 + r (lanes 0..31 of wave 0 write it)
+    auto tab_load = [&](int tile, float &qsn, unsigned &taun) __attribute__((always_inline)) {
+        const int qn = tile * 32 + r;
+        qsn = qn < nq ? query_scale[qn] : 0.0f;
+        taun = qn < nq ? tau[qn] : 0xFFFFFFFFu;
+    };
+    auto tab_store = [&](int tile, int buf, float qsn, unsigned taun) __attribute__((always_inline)) {
+        float thr = __builtin_inff();
+        if (tile * 32 + r < nq) {
+            thr = -__builtin_inff();
+            if (qsn > 0.0f) {
+                const float x = (__uint_as_float(taun) / qsn) * 0.99999905f;  // 1 - 2^-20
+                if (x >= 1e-30f && x < 3e38f) thr = x;
+            }
+        }
+        tab[buf].thr[r] = thr;
+        tab[buf].qs[r] = qsn;
+        tab[buf].tau[r] = taun;
+    };
+    int cnt = 0;  // entries in my wave's survivor list (wave-uniform)
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int i = lane; i < cnt; i += 64) {
+            const uint2 e = cb[wv][i];
+            const int q = (int)(e.x >> 6);
+            const int p = atomicAdd(&buf_cnt[q * DENSE_CNT_STRIDE], 1);
+            if (p < cap) {
+                buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d0 + (int)(e.x & 63u));
+                buf_score[(int64_t)q * cap + p] = __uint_as_float(e.y);
+            } else {
+                ovf[q] = 1;
+                *any_ovf = 1;
+            }
+        }
+        cnt = 0;
+    };
     stage_tile(0, 0);
+    if (wv == 0 && h == 0) {
+        float qsn;
+        unsigned taun;
+        tab_load(0, qsn, taun);
+        tab_store(0, 0, qsn, taun);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int qt = 0; qt < n_qt; ++qt) {
         const int q0 = qt * 32;
-        const int qa = q0 + r;
         const int cur = qt & 1;
-        if (qt + 1 < n_qt) stage_tile(qt + 1, cur ^ 1);  // uniform; the other buffer was last read one barrier ago
+        const bool more = qt + 1 < n_qt;  // uniform
+        float qsn = 0.0f;
+        unsigned taun = 0u;
+        if (more) {
+            stage_tile(qt + 1, cur ^ 1);  // the other buffer was last read one barrier ago
+            if (wv == 0 && h == 0) tab_load(qt + 1, qsn, taun);
+        }
         v16i acc[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -148,62 +214,53 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
 #pragma unroll
             for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][s], acc[t], 0, 0, 0);
         }
-        // the tile's 32 query scales and thresholds: one coalesced load each, then a lane permute per accumulator row
-        const float qs_mine = qa < nq ? query_scale[qa] : 0.0f;
-        const unsigned tau_mine = qa < nq ? tau[qa] : 0xFFFFFFFFu;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-            // Survivors of one 32 x 32 tile.  Three phases so that the (returning) atomics of all 16 accumulator
-            // registers are in flight together -- one global round trip per tile instead of one per register with
-            // survivors: scores + pass bits; one atomicAdd per (query row, lane half) with survivors; broadcast the
-            // bases and store.
-            const int64_t d = d0 + 32 * t + r;
-            float scv[16];
-            unsigned passbits = 0;
+            const double ds = (double)dsf[t];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // differs between the two lane halves
-                const float qsr = __shfl(qs_mine, row);
-                const unsigned taur = (unsigned)__shfl((int)tau_mine, row);
-                scv[reg] = dok[t] ? (float)(((double)acc[t][reg] * (double)qsr) * ds[t]) : 0.0f;
-                if (q0 + row < nq && scv[reg] > 0.0f && __float_as_uint(scv[reg]) >= taur) passbits |= 1u << reg;
-            }
-            if (__ballot(passbits != 0u) != 0ull) {  // uniform; about 6 survivors per tile at the design point
-                int basev[16];
+            for (int g = 0; g < 4; ++g) {
+                // accumulator registers 4 g .. 4 g + 3 are query rows 8 g + 4 h + 0 .. 3: their bounds are one 16-byte LDS read
+                const float4 th = *reinterpret_cast<const float4 *>(&tab[cur].thr[8 * g + 4 * h]);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const bool pass = (passbits >> reg) & 1u;
-                    const unsigned long long m = __ballot(pass);
-                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);  // my half's survivors: one query row
-                    basev[reg] = 0;
-                    if (pass && (mh & ((1u << r) - 1u)) == 0u)  // first survivor of the row reserves room for all of them
-                        basev[reg] = atomicAdd(&buf_cnt[(q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * DENSE_CNT_STRIDE], __popc(mh));
-                }
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const bool pass = (passbits >> reg) & 1u;
-                    const unsigned long long m = __ballot(pass);
-                    if (m != 0ull) {  // uniform
-                        const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)(m & 0xFFFFFFFFull);
-                        const int base = __shfl(basev[reg], h * 32 + (mh ? __ffs((int)mh) - 1 : 0));
-                        if (pass) {
-                            const int q = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                            const int p = base + __popc(mh & ((1u << r) - 1u));
-                            if (p < cap) {
-                                buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d);
-                                buf_score[(int64_t)q * cap + p] = scv[reg];
-                            } else {
-                                ovf[q] = 1;
-                                *any_ovf = 1;
+                for (int j = 0; j < 4; ++j) {
+                    const int reg = 4 * g + j;
+                    const float a = (float)acc[t][reg] * dsf[t];
+                    const bool scr = a >= thv[j];
+                    if (__ballot(scr) != 0ull) {  // uniform
+                        const int row = 8 * g + 4 * h + j;
+                        const float qsr = tab[cur].qs[row];
+                        const unsigned taur = tab[cur].tau[row];
+                        const float sc = (float)(((double)acc[t][reg] * (double)qsr) * ds);
+                        const bool pass = scr && q0 + row < nq && sc > 0.0f && __float_as_uint(sc) >= taur;
+                        const unsigned long long m = __ballot(pass);
+                        if (m != 0ull) {  // uniform
+                            const int n = __popcll(m);
+                            if (cnt + n <= DENSE_CB) {
+                                if (pass) cb[wv][cnt + (int)lane_rank(m)] = make_uint2(((unsigned)(q0 + row) << 6) | (unsigned)(32 * t + r), __float_as_uint(sc));
+                                cnt += n;
+                            } else if (pass) {  // list full inside one tile (degenerate score distributions): straight to the buffer
+                                const int q = q0 + row;
+                                const int p = atomicAdd(&buf_cnt[q * DENSE_CNT_STRIDE], 1);
+                                if (p < cap) {
+                                    buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d0 + 32 * t + r);
+                                    buf_score[(int64_t)q * cap + p] = sc;
+                                } else {
+                                    ovf[q] = 1;
+                                    *any_ovf = 1;
+                                }
                             }
                         }
                     }
                 }
             }
         }
+        if (cnt >= DENSE_CB / 2) flush();  // uniform
+        if (more && wv == 0 && h == 0) tab_store(qt + 1, cur ^ 1, qsn, taun);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the next tile has landed in LDS
-        __syncthreads();  // the next tile's fragments are in LDS, this tile's buffer is free
+        __syncthreads();  // the next tile's fragments and table are in LDS, this tile's buffers are free
     }
+    if (cnt > 0) flush();
 }
 
 // Row top-k: one workgroup per (query, split of the doc range) folds its slice of the score row into an exact lazy
@@ -402,7 +459,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
         if (S > 0) {
             // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
             HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(S), corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, dim3(blocks_for(S), (unsigned)((qb + 127) / 128)), corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,

@@ -129,6 +129,38 @@ def test_dense_int8_candidate_overflow_falls_back():
 
 
 @pytest.mark.gpu
+def test_dense_int8_screen_edge_cases():
+    """The fused filter screens accumulator rows in fp32 before the exact fp64 chain (csrc/dense.hip): cases that sit on the
+    screen's edges -- few distinct dot products (whole groups of docs tie with the threshold exactly), scales spread over 40
+    orders of magnitude, zero / negative / denormal scales (no screen for such a query; a negative scale flips the sign of the
+    scores: negative dot products then rank) -- must still be the oracle's rows bit for bit."""
+    rng = np.random.default_rng(2027)
+    for n_docs, dim, nq, k, lohi in ((80_000, 32, 40, 100, 3), (70_001, 64, 33, 10, 2), (66_000, 768, 36, 64, 128)):
+        c = rng.integers(-lohi + 1, lohi, (n_docs, dim)).astype(np.int8)
+        q = rng.integers(-lohi + 1, lohi, (nq, dim)).astype(np.int8)
+        for scales in ("flat", "wild"):
+            if scales == "flat":
+                cs = np.ones(n_docs, np.float32)
+                qs = np.ones(nq, np.float32)
+            else:
+                cs = (10.0 ** rng.integers(-18, 18, n_docs)).astype(np.float32) * (rng.random(n_docs) + 0.5).astype(np.float32)
+                qs = (10.0 ** rng.integers(-18, 18, nq)).astype(np.float32)
+                cs[::11] = 0.0
+                cs[3::13] *= -1.0
+                cs[5::17] = np.float32(1e-41)  # denormal
+            qs[1] = 0.0
+            qs[2] = -qs[2]
+            qs[4] = np.float32(1e-42)
+            ix = sparse_rx.DenseInt8Index(c, cs)
+            d, s, n = ix.search(q, qs, k)
+            with np.errstate(over="ignore", under="ignore"):
+                ed, es, en = np_oracle.dense_topk(np_oracle.int8_similarities(q, c, qs, cs), k)
+            assert np.array_equal(n, en), (n_docs, dim, scales)
+            assert np.array_equal(s.view(np.uint32), es.view(np.uint32)), (n_docs, dim, scales)
+            assert np.array_equal(d, ed), (n_docs, dim, scales)
+
+
+@pytest.mark.gpu
 def test_dense_f32_search_by_vector():
     """srx_dense_search_f32 against np.dot(embedding_index, query_vector) (retrieval.py:411-423) -- the call the
     reference makes; its BLAS summation order is unspecified, so: scores within 1e-5 relative of the float64 value
