@@ -101,11 +101,28 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 //    and at the end: one global round trip per few hundred survivors instead of one per tile.
 struct DenseTileTab {
     float thr[32];  // the screen's bound on fl32(acc) * ds; -inf = not screened, +inf = no such query
-    float qs[32];
     unsigned tau[32];
+    double qs[32];
 };
+// ds_read_b128 with a compile-time offset, issued where it stands (the scheduler sinks plain LDS reads down to one MFMA before
+// their use); the consumer waits with lds_wait<N>, which also ties the value to the wait
+template <int OFF>
+__device__ __forceinline__ void lds_read128(v4i &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(v4i &x) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <int KS>
-__global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
                                                                        int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
             }
         }
         tab[buf].thr[r] = thr;
-        tab[buf].qs[r] = qsn;
+        tab[buf].qs[r] = (double)qsn;
         tab[buf].tau[r] = taun;
     };
     int cnt = 0;  // entries in my wave's survivor list (wave-uniform)
@@ -208,20 +225,35 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
         v16i acc[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // A fragments: PF LDS reads in flight ahead of the MFMA that consumes them (an LDS read returns after ~100+ cycles, an
+        // MFMA issues every 32: the compiler's read-one-ahead schedule left the matrix pipe idle most of the time).  LDS reads
+        // return in order, so before step s at most min(PF - 1, KS - 1 - s) younger reads may still be out.
+        constexpr int PF = KS < 6 ? KS : 6;
+        v4i Ab[PF];
+        const unsigned a_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&ldsA[cur][lane];
+        static_for<0, PF>([&](auto i) { lds_read128<decltype(i)::value * 1024>(Ab[decltype(i)::value], a_addr); });
+        static_for<0, KS>([&](auto i) {
+            constexpr int s = decltype(i)::value;
+            lds_wait<(KS - 1 - s < PF - 1 ? KS - 1 - s : PF - 1)>(Ab[s % PF]);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const v4i A = ldsA[cur][s * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][s], acc[t], 0, 0, 0);
-        }
+            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ab[s % PF], B[t][s], acc[t], 0, 0, 0);
+            if constexpr (s + PF < KS) lds_read128<(s + PF) * 1024>(Ab[s % PF], a_addr);
+        });
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const double ds = (double)dsf[t];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // accumulator registers 4 g .. 4 g + 3 are query rows 8 g + 4 h + 0 .. 3: their bounds are one 16-byte LDS read
+                // (with the rows' thresholds and fp64 scales: a read inside the exact branch put two LDS round trips into every
+                // one of them, at two waves per SIMD)
                 const float4 th = *reinterpret_cast<const float4 *>(&tab[cur].thr[8 * g + 4 * h]);
+                const uint4 ta = *reinterpret_cast<const uint4 *>(&tab[cur].tau[8 * g + 4 * h]);
+                const double2 qa = *reinterpret_cast<const double2 *>(&tab[cur].qs[8 * g + 4 * h]);
+                const double2 qb = *reinterpret_cast<const double2 *>(&tab[cur].qs[8 * g + 4 * h + 2]);
                 const float thv[4] = {th.x, th.y, th.z, th.w};
+                const unsigned tav[4] = {ta.x, ta.y, ta.z, ta.w};
+                const double qsv[4] = {qa.x, qa.y, qb.x, qb.y};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int reg = 4 * g + j;
@@ -229,9 +261,8 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_filter_kernel(const int8
                     const bool scr = a >= thv[j];
                     if (__ballot(scr) != 0ull) {  // uniform
                         const int row = 8 * g + 4 * h + j;
-                        const float qsr = tab[cur].qs[row];
-                        const unsigned taur = tab[cur].tau[row];
-                        const float sc = (float)(((double)acc[t][reg] * (double)qsr) * ds);
+                        const unsigned taur = tav[j];
+                        const float sc = (float)(((double)acc[t][reg] * qsv[j]) * ds);
                         const bool pass = scr && q0 + row < nq && sc > 0.0f && __float_as_uint(sc) >= taur;
                         const unsigned long long m = __ballot(pass);
                         if (m != 0ull) {  // uniform
@@ -269,7 +300,8 @@ constexpr int DENSE_NPT = 16;
 // mode 0: rank scores[q][lo..hi) (ids = doc_base + column).  mode 1: rank the query's candidate buffer (buf_doc /
 // scores hold (doc, score) pairs, buf_cnt[q] of them).  only_flag: +1 = only queries with ovf[q] != 0, -1 = only queries
 // with ovf[q] == 0, 0 = all; a skipped query writes count -1 for its first list (the merge kernels then leave its
-// output row alone).  tau_out (optional): the k-th best score's bits when the list holds k entries, else 0.
+// output row alone).  tau_out (optional): the k-th best score's bits when the list holds k entries, else 0 (tau_keep: the
+// larger of that and the value already there).
 __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_docs,
                                                                  int nq, int k, int n_splits, int64_t doc_base, int mode,
                                                                  const int32_t *__restrict__ buf_doc,
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__
                                                                  int32_t *__restrict__ cand_doc,
                                                                  float *__restrict__ cand_score,
                                                                  int32_t *__restrict__ cand_count,
-                                                                 unsigned *__restrict__ tau_out) {
+                                                                 unsigned *__restrict__ tau_out, int tau_keep) {
     __shared__ MergeShared M;
     const int tid = threadIdx.x;
     const int q = blockIdx.x / n_splits, split = blockIdx.x - q * n_splits;
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_topk_kernel(const float *__
     if (tid == 0) cand_count[blockIdx.x] = (int)cnt;
     if (tau_out != nullptr) {  // n_splits == 1 here
         const SumMaxMin rr = block_sum_max_min(0u, 0u, mn, M.tk.red);
-        if (tid == 0) tau_out[q] = cnt >= (unsigned)k ? rr.mn : 0u;
+        if (tid == 0) tau_out[q] = max(tau_keep ? tau_out[q] : 0u, cnt >= (unsigned)k ? rr.mn : 0u);
     }
 }
 
@@ -463,12 +495,30 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
-                               w.cand_score, w.cand_count, w.tau);
-            SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (dim / 32 <= 12 ? blocks_for((n_docs + 1) / 2) : blocks_for(n_docs)), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.tau,
-                               DENSE_CAP, doc_base, w.buf_doc, w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
+                               w.cand_score, w.cand_count, w.tau, 0);
+            // Two rounds (round 3): the sample's threshold lets about k n / S docs per query through; the first round filters only
+            // the docs [0, S1), S1 = sqrt(S n), the k-th best of its survivors (a valid lower bound too, and never below the
+            // sample's) is the threshold of the second round over [S1, n): about k (S1 / S + n / S1) survivors per query instead
+            // of k n / S -- 4x fewer exact-path rows and buffer appends at 1 M docs.  Both rounds append to the same buffers.
+            const int64_t docs_per_block = (dim / 32 <= 12 ? 64 : 32) * WAVES;
+            int64_t S1 = (int64_t)sqrt((double)S * (double)n_docs);
+            const int64_t chip = docs_per_block * 512;  // two workgroups on each of the 256 CUs: whole rounds of the chip
+            S1 = S1 >= chip ? (S1 + chip - 1) / chip * chip : (S1 + docs_per_block - 1) / docs_per_block * docs_per_block;
+            if (S1 * 2 > n_docs) S1 = n_docs;  // small corpus: one round
+            for (int round = 0; round < 2; ++round) {
+                const int64_t lo = round == 0 ? 0 : S1, hi = round == 0 ? S1 : n_docs;
+                if (lo >= hi) break;
+                SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (unsigned)((hi - lo + docs_per_block - 1) / docs_per_block), corpus + lo * dim,
+                                   corpus_scale + lo, hi - lo, (const v4i *)w.apack, qs, qb, w.tau, DENSE_CAP, doc_base + lo, w.buf_doc,
+                                   w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
+                if (round == 0 && hi < n_docs)
+                    hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
+                                       n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, (const int *)nullptr, 0, no_gate,
+                                       w.cand_doc, w.cand_score, w.cand_count, w.tau, 1);
+            }
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
                                n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, w.ovf, -1, no_gate, w.cand_doc,
-                               w.cand_score, w.cand_count, (unsigned *)nullptr);
+                               w.cand_score, w.cand_count, (unsigned *)nullptr, 0);
             HIP_TRY(hipGetLastError());
             int rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, 1, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
                                 (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
@@ -479,7 +529,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
                                (const int *)w.any_ovf);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
-                               (const int *)w.any_ovf, w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+                               (const int *)w.any_ovf, w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr, 0);
             HIP_TRY(hipGetLastError());
             rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
                             (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
@@ -489,7 +539,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
-                               w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr);
+                               w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr, 0);
             HIP_TRY(hipGetLastError());
             const int rc = srx_merge_impl(device, w.cand_doc, w.cand_score, w.cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1, od, os, oc,
                                       (int64_t)k, (int64_t)1, nullptr, 0, stream_v);
@@ -642,7 +692,7 @@ int dense_rows_search(const char *who, int32_t device, const void *rows, const f
                                u8_scale_min, n_docs, (int)dim, queries + (int64_t)q0 * dim, qb, scores, ld);
         hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, scores, ld, n_docs, qb, k,
                            ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0,
-                           (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr);
+                           (const int *)nullptr, cand_doc, cand_score, cand_count, (unsigned *)nullptr, 0);
         HIP_TRY(hipGetLastError());
         const int rc = srx_merge_impl(device, cand_doc, cand_score, cand_count, qb, ns, k, 0, (int64_t)k, (int64_t)1,
                                   out_doc + (int64_t)q0 * k, out_score + (int64_t)q0 * k, out_count + q0, (int64_t)k, (int64_t)1,
