@@ -12,6 +12,12 @@
 namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+#ifndef SRX_DENSE_NW_LONG
+#define SRX_DENSE_NW_LONG 4  // waves per workgroup of the filter kernel on rows longer than 384 bytes (8: measured, no gain)
+#endif
+#ifndef SRX_DENSE_PF
+#define SRX_DENSE_PF 6  // LDS reads of query fragments in flight ahead of the MFMAs
+#endif
 constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate counters: one 128-byte line each (all waves
                                       // add to these: counters sharing a line serialise in one L2 channel)
 
@@ -99,11 +105,29 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 //  * survivors go to a per-wave LDS list ((query, doc-in-wave), score: 8 bytes) -- wave ballot + mbcnt, no atomics -- and
 //    the list is flushed to the queries' global buffers (one returning atomicAdd per entry, 64 in flight) when half full
 //    and at the end: one global round trip per few hundred survivors instead of one per tile.
-struct DenseTileTab {
-    float thr[32];  // the screen's bound on fl32(acc) * ds; -inf = not screened, +inf = no such query
-    unsigned tau[32];
-    double qs[32];
+struct DenseTab {    // per query of the pass (<= 1 024)
+    float thr[1024];  // the screen's bound on fl32(acc) * ds; -inf = not screened, +inf = no such query
+    unsigned tau[1024];
+    float qs[1024];
 };
+// In-kernel stamps of the filter kernel (diagnostic build -DSRX_DSTAMP, tools/dense_stamp_run.py): s_memtime ticks per phase,
+// summed over waves.
+#ifdef SRX_DSTAMP
+__device__ unsigned long long g_dstamp[16];
+#define DSTAMP(i)                                                                        \
+    do {                                                                                 \
+        unsigned long long t_;                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        dst_acc[i] += t_ - dst_prev;                                                     \
+        dst_prev = t_;                                                                   \
+    } while (0)
+#else
+#define DSTAMP(i) \
+    do {          \
+    } while (0)
+#endif
 // ds_read_b128 with a compile-time offset, issued where it stands (the scheduler sinks plain LDS reads down to one MFMA before
 // their use); the consumer waits with lds_wait<N>, which also ties the value to the wait
 template <int OFF>
@@ -122,7 +146,7 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 template <int KS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
+__global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute__((amdgpu_waves_per_eu(2))) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
                                                                        int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
@@ -134,14 +158,60 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) vo
     // DT doc tiles of 32 per wave: with two, every A fragment (query tile) feeds two MFMAs; the B fragments of both
     // tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
     constexpr int DT = KS <= 12 ? 2 : 1;
-    constexpr int DENSE_CB = KS > 24 ? 256 : 512;  // per-wave survivor list entries (two workgroups per CU must fit the LDS)
-    __shared__ v4i ldsA[2][KS * 64];
-    __shared__ DenseTileTab tab[2];
-    __shared__ uint2 cb[WAVES][DENSE_CB];
+    constexpr int NW = KS > 12 ? SRX_DENSE_NW_LONG : 4;  // waves per workgroup
+    // LDS: two workgroups of four waves per CU must fit (80 KiB each); one of eight waves may take more
+    constexpr int DENSE_CB = KS <= 12 ? 512 : (KS <= 24 ? 256 : 128);  // per-wave survivor list entries
+    constexpr int NBUF = (KS <= 16 || NW == 8) ? 3 : 2;  // query tiles in LDS: the one in use and one or two on their way
+    constexpr int PD = NBUF - 1;                         // tiles staged ahead
+    constexpr int ROWS = (KS + NW - 1) / NW;             // 1 KiB fragment rows of a tile that one wave stages
+    __shared__ v4i ldsA[NBUF][KS * 64];
+    __shared__ DenseTab tab;
+    __shared__ uint2 cb[NW][DENSE_CB];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wv = threadIdx.x >> 6;
-    const int64_t d0 = ((int64_t)blockIdx.x * WAVES + wv) * (32 * DT);  // may lie past the corpus: the wave then only helps
-    constexpr int DIM = KS * 32;                                          // staging and takes part in the barriers
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in a scalar register: the staging addresses are then scalar
+    const int64_t d0 = ((int64_t)blockIdx.x * NW + wv) * (32 * DT);  // may lie past the corpus: the wave then only helps
+    constexpr int DIM = KS * 32;                                      // staging and takes part in the barriers
+    const int n_qt = (nq + 31) / 32;
+#ifdef SRX_DSTAMP
+    unsigned long long dst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dst_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst_prev)::"memory");
+#endif
+    // global -> LDS without a trip through registers (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's
+    // LDS base + 16 l): wave w copies the 64-fragment rows w, w + NW, ... of the tile -- EXACTLY ROWS loads per wave and tile
+    // (a wave with a row too many re-copies the tile's last row: same bytes, same place), so that the wait for a tile can be a
+    // counted one: with three buffers the loads of the tile after it stay in flight across the barrier.
+    // (Measured and dropped: staging through registers -- global_load_dwordx4 at the top of a tile, ds_write_b128 at its end.
+    // In-kernel stamps put 100-200 cycles on the issue of each staging load either way, ~1 300 cycles per 768-byte-row tile;
+    // the register form was 3 % slower end to end.)
+    auto stage_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            const int s = min(wv + row * NW, KS - 1);                    // scalar
+            const v4i *src = apack + ((int64_t)tile * KS + s) * 64;  // scalar base + a 32-bit lane offset
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane),
+                                             (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (i < n_qt) stage_tile(i, i);
+    // every query's screen bound, threshold and scale, once per workgroup (12 KiB of LDS for 1 024 queries)
+    for (int q = threadIdx.x; q < n_qt * 32; q += NW * 64) {
+        float thr = __builtin_inff(), qsn = 0.0f;
+        unsigned taun = 0xFFFFFFFFu;
+        if (q < nq) {
+            qsn = query_scale[q];
+            taun = tau[q];
+            thr = -__builtin_inff();
+            if (qsn > 0.0f) {
+                const float x = (__uint_as_float(taun) / qsn) * 0.99999905f;  // 1 - 2^-20
+                if (x >= 1e-30f && x < 3e38f) thr = x;
+            }
+        }
+        tab.thr[q] = thr;
+        tab.qs[q] = qsn;
+        tab.tau[q] = taun;
+    }
     v4i B[DT][KS];
     float dsf[DT];
 #pragma unroll
@@ -155,39 +225,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) vo
         }
         dsf[t] = dok ? corpus_scale[d] : 0.0f;  // 0: every score of a row past the corpus is 0 or NaN, never > 0
     }
-    const int n_qt = (nq + 31) / 32;
-    // global -> LDS without a trip through registers (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's
-    // LDS base + 16 l): wave w copies the 64-fragment rows w, w + 4, ... of the tile; no staging VGPRs (with them the kernel
-    // needed 258 registers and fell to one wave per SIMD)
-    auto stage_tile = [&](int tile, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int row = 0; row < (KS + WAVES - 1) / WAVES; ++row) {
-            const int s = wv + row * WAVES;
-            if (s < KS)  // uniform per wave
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(apack + ((int64_t)tile * KS + s) * 64 + lane),
-                                                 (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
-        }
-    };
-    // the tile's table row of query tile * 32 + r (lanes 0..31 of wave 0 write it)
-    auto tab_load = [&](int tile, float &qsn, unsigned &taun) __attribute__((always_inline)) {
-        const int qn = tile * 32 + r;
-        qsn = qn < nq ? query_scale[qn] : 0.0f;
-        taun = qn < nq ? tau[qn] : 0xFFFFFFFFu;
-    };
-    auto tab_store = [&](int tile, int buf, float qsn, unsigned taun) __attribute__((always_inline)) {
-        float thr = __builtin_inff();
-        if (tile * 32 + r < nq) {
-            thr = -__builtin_inff();
-            if (qsn > 0.0f) {
-                const float x = (__uint_as_float(taun) / qsn) * 0.99999905f;  // 1 - 2^-20
-                if (x >= 1e-30f && x < 3e38f) thr = x;
-            }
-        }
-        tab[buf].thr[r] = thr;
-        tab[buf].qs[r] = (double)qsn;
-        tab[buf].tau[r] = taun;
-    };
-    int cnt = 0;  // entries in my wave's survivor list (wave-uniform)
+    int cnt = 0;         // entries in my wave's survivor list (wave-uniform)
+    bool dirty = false;  // stores / atomics of mine may be in flight (wave-uniform): the next wait for a staged tile drains them
     auto flush = [&]() __attribute__((always_inline)) {
         for (int i = lane; i < cnt; i += 64) {
             const uint2 e = cb[wv][i];
@@ -202,35 +241,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) vo
             }
         }
         cnt = 0;
+        dirty = true;
     };
-    stage_tile(0, 0);
-    if (wv == 0 && h == 0) {
-        float qsn;
-        unsigned taun;
-        tab_load(0, qsn, taun);
-        tab_store(0, 0, qsn, taun);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DSTAMP(0);  // prologue: B fragments, table, first tile staged
     for (int qt = 0; qt < n_qt; ++qt) {
         const int q0 = qt * 32;
-        const int cur = qt & 1;
-        const bool more = qt + 1 < n_qt;  // uniform
-        float qsn = 0.0f;
-        unsigned taun = 0u;
-        if (more) {
-            stage_tile(qt + 1, cur ^ 1);  // the other buffer was last read one barrier ago
-            if (wv == 0 && h == 0) tab_load(qt + 1, qsn, taun);
-        }
+        const int cur = qt % NBUF;
+        const bool more = qt + PD < n_qt;                  // uniform
+        if (more) stage_tile(qt + PD, (qt + PD) % NBUF);  // that buffer was last read in tile qt - 1: one barrier ago
+        DSTAMP(1);  // stage issue
         v16i acc[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // A fragments: PF LDS reads in flight ahead of the MFMA that consumes them (an LDS read returns after ~100+ cycles, an
-        // MFMA issues every 32: the compiler's read-one-ahead schedule left the matrix pipe idle most of the time).  LDS reads
-        // return in order, so before step s at most min(PF - 1, KS - 1 - s) younger reads may still be out.
-        constexpr int PF = KS < 6 ? KS : 6;
-        v4i Ab[PF];
+        // The tile's 32 screen bounds (rows 8 g + 4 h + 0..3 are accumulator registers 4 g .. 4 g + 3) and the A fragments: LDS
+        // reads issued where they stand, PF of the latter in flight ahead of the MFMA that consumes them (an LDS read returns after
+        // ~100+ cycles, an MFMA issues every 32; the compiler's schedule reads one ahead and puts each group's bounds right before
+        // their use: four more LDS round trips per tile).  LDS reads return in order, so before step s at most
+        // min(PF - 1, KS - 1 - s) younger reads may still be out.
+        constexpr int PF = KS < SRX_DENSE_PF ? KS : SRX_DENSE_PF;
+        v4i Ab[PF], thb[4];
         const unsigned a_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&ldsA[cur][lane];
+        const unsigned t_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&tab.thr[q0 + 4 * h];
+        static_for<0, 4>([&](auto g) { lds_read128<decltype(g)::value * 32>(thb[decltype(g)::value], t_addr); });
         static_for<0, PF>([&](auto i) { lds_read128<decltype(i)::value * 1024>(Ab[decltype(i)::value], a_addr); });
         static_for<0, KS>([&](auto i) {
             constexpr int s = decltype(i)::value;
@@ -239,46 +273,50 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) vo
             for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ab[s % PF], B[t][s], acc[t], 0, 0, 0);
             if constexpr (s + PF < KS) lds_read128<(s + PF) * 1024>(Ab[s % PF], a_addr);
         });
+        DSTAMP(2);  // MFMA loop (to the issue of the last one)
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const double ds = (double)dsf[t];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // accumulator registers 4 g .. 4 g + 3 are query rows 8 g + 4 h + 0 .. 3: their bounds are one 16-byte LDS read
-                // (with the rows' thresholds and fp64 scales: a read inside the exact branch put two LDS round trips into every
-                // one of them, at two waves per SIMD)
-                const float4 th = *reinterpret_cast<const float4 *>(&tab[cur].thr[8 * g + 4 * h]);
-                const uint4 ta = *reinterpret_cast<const uint4 *>(&tab[cur].tau[8 * g + 4 * h]);
-                const double2 qa = *reinterpret_cast<const double2 *>(&tab[cur].qs[8 * g + 4 * h]);
-                const double2 qb = *reinterpret_cast<const double2 *>(&tab[cur].qs[8 * g + 4 * h + 2]);
-                const float thv[4] = {th.x, th.y, th.z, th.w};
+                // "not below" instead of ">=": a NaN (0 * inf, a NaN scale) goes to the exact arithmetic too
+                const float thv[4] = {__int_as_float(thb[g].x), __int_as_float(thb[g].y), __int_as_float(thb[g].z), __int_as_float(thb[g].w)};
+                unsigned long long mk[4];  // lane masks in scalar registers: v_cmp writes them, s_or combines them
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[j] = __ballot(!((float)acc[t][4 * g + j] * dsf[t] < thv[j]));
+                if ((mk[0] | mk[1] | mk[2] | mk[3]) == 0ull) continue;  // uniform: most groups of four end here
+                // the rows' thresholds and fp64 scales, read once per group (a read inside every exact branch put two LDS round
+                // trips into each of them, at two waves per SIMD)
+                const uint4 ta = *reinterpret_cast<const uint4 *>(&tab.tau[q0 + 8 * g + 4 * h]);
+                const float4 qa = *reinterpret_cast<const float4 *>(&tab.qs[q0 + 8 * g + 4 * h]);
                 const unsigned tav[4] = {ta.x, ta.y, ta.z, ta.w};
-                const double qsv[4] = {qa.x, qa.y, qb.x, qb.y};
+                const float qsv[4] = {qa.x, qa.y, qa.z, qa.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int reg = 4 * g + j;
-                    const float a = (float)acc[t][reg] * dsf[t];
-                    const bool scr = a >= thv[j];
-                    if (__ballot(scr) != 0ull) {  // uniform
+                    if (mk[j] != 0ull) {  // uniform
                         const int row = 8 * g + 4 * h + j;
                         const unsigned taur = tav[j];
-                        const float sc = (float)(((double)acc[t][reg] * qsv[j]) * ds);
-                        const bool pass = scr && q0 + row < nq && sc > 0.0f && __float_as_uint(sc) >= taur;
+                        const float sc = (float)(((double)acc[t][reg] * (double)qsv[j]) * ds);
+                        const bool pass = !((float)acc[t][reg] * dsf[t] < thv[j]) && q0 + row < nq && sc > 0.0f && __float_as_uint(sc) >= taur;
                         const unsigned long long m = __ballot(pass);
                         if (m != 0ull) {  // uniform
                             const int n = __popcll(m);
                             if (cnt + n <= DENSE_CB) {
                                 if (pass) cb[wv][cnt + (int)lane_rank(m)] = make_uint2(((unsigned)(q0 + row) << 6) | (unsigned)(32 * t + r), __float_as_uint(sc));
                                 cnt += n;
-                            } else if (pass) {  // list full inside one tile (degenerate score distributions): straight to the buffer
-                                const int q = q0 + row;
-                                const int p = atomicAdd(&buf_cnt[q * DENSE_CNT_STRIDE], 1);
-                                if (p < cap) {
-                                    buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d0 + 32 * t + r);
-                                    buf_score[(int64_t)q * cap + p] = sc;
-                                } else {
-                                    ovf[q] = 1;
-                                    *any_ovf = 1;
+                            } else {  // list full inside one tile (degenerate score distributions): straight to the buffer
+                                dirty = true;
+                                if (pass) {
+                                    const int q = q0 + row;
+                                    const int p = atomicAdd(&buf_cnt[q * DENSE_CNT_STRIDE], 1);
+                                    if (p < cap) {
+                                        buf_doc[(int64_t)q * cap + p] = (int32_t)(doc_base + d0 + 32 * t + r);
+                                        buf_score[(int64_t)q * cap + p] = sc;
+                                    } else {
+                                        ovf[q] = 1;
+                                        *any_ovf = 1;
+                                    }
                                 }
                             }
                         }
@@ -286,12 +324,27 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2))) vo
                 }
             }
         }
+        DSTAMP(3);  // epilogue (waits for the accumulators first)
         if (cnt >= DENSE_CB / 2) flush();  // uniform
-        if (more && wv == 0 && h == 0) tab_store(qt + 1, cur ^ 1, qsn, taun);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the next tile has landed in LDS
-        __syncthreads();  // the next tile's fragments and table are in LDS, this tile's buffers are free
+        // my share of tile qt + 1 has landed (with three buffers it was issued a whole tile ago, and the loads of tile qt + 2 stay
+        // in flight).  Loads return in order; stores / atomics of mine (a flush) may not, so after one everything is drained.
+        if (PD > 1 && more && !dirty)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * ROWS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dirty = false;
+        DSTAMP(4);  // flush, wait for the staged tile
+        __syncthreads();  // every wave's share of tile qt + 1 is in LDS; tile qt's buffer is free
+        DSTAMP(5);  // barrier
     }
     if (cnt > 0) flush();
+    DSTAMP(6);  // final flush
+#ifdef SRX_DSTAMP
+    if (lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_dstamp[i], dst_acc[i]);
+        atomicAdd(&g_dstamp[8], 1ull);
+    }
+#endif
 }
 
 // Row top-k: one workgroup per (query, split of the doc range) folds its slice of the score row into an exact lazy
@@ -465,18 +518,18 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
     auto blocks_for = [](int64_t docs) { return (unsigned)((docs + 32 * WAVES - 1) / (32 * WAVES)); };
     int ks_ok = 1;
     // KERNEL<KS> dispatch on dim / 32
-#define SRX_DENSE_DISPATCH(KERNEL, GRID, ...)                                                                         \
+#define SRX_DENSE_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                                        \
     switch (dim / 32) {                                                                                               \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;                \
-        case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
-        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
-        case 24: hipLaunchKernelGGL(KERNEL<24>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
-        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(THREADS), 0, stream, __VA_ARGS__); break;              \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;                \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;              \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;              \
+        case 24: hipLaunchKernelGGL(KERNEL<24>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;              \
+        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(BLOCK), 0, stream, __VA_ARGS__); break;              \
         default: ks_ok = 0;                                                                                           \
     }
     for (int q0 = 0; q0 < nq; q0 += QB) {
@@ -491,7 +544,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
         if (S > 0) {
             // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
             HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, dim3(blocks_for(S), (unsigned)((qb + 127) / 128)), corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, dim3(blocks_for(S), (unsigned)((qb + 127) / 128)), THREADS, corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
@@ -500,15 +553,16 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             // the docs [0, S1), S1 = sqrt(S n), the k-th best of its survivors (a valid lower bound too, and never below the
             // sample's) is the threshold of the second round over [S1, n): about k (S1 / S + n / S1) survivors per query instead
             // of k n / S -- 4x fewer exact-path rows and buffer appends at 1 M docs.  Both rounds append to the same buffers.
-            const int64_t docs_per_block = (dim / 32 <= 12 ? 64 : 32) * WAVES;
+            const int filter_threads = dim / 32 > 12 ? 64 * SRX_DENSE_NW_LONG : 256;  // srx_dense_i8_filter_kernel: eight waves per workgroup on long rows
+            const int64_t docs_per_block = dim / 32 <= 12 ? 64 * 4 : 32 * SRX_DENSE_NW_LONG;
             int64_t S1 = (int64_t)sqrt((double)S * (double)n_docs);
-            const int64_t chip = docs_per_block * 512;  // two workgroups on each of the 256 CUs: whole rounds of the chip
+            const int64_t chip = docs_per_block * (dim / 32 > 12 ? 2048 / SRX_DENSE_NW_LONG : 512);  // whole rounds of the chip (8 waves per CU)
             S1 = S1 >= chip ? (S1 + chip - 1) / chip * chip : (S1 + docs_per_block - 1) / docs_per_block * docs_per_block;
             if (S1 * 2 > n_docs) S1 = n_docs;  // small corpus: one round
             for (int round = 0; round < 2; ++round) {
                 const int64_t lo = round == 0 ? 0 : S1, hi = round == 0 ? S1 : n_docs;
                 if (lo >= hi) break;
-                SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (unsigned)((hi - lo + docs_per_block - 1) / docs_per_block), corpus + lo * dim,
+                SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (unsigned)((hi - lo + docs_per_block - 1) / docs_per_block), filter_threads, corpus + lo * dim,
                                    corpus_scale + lo, hi - lo, (const v4i *)w.apack, qs, qb, w.tau, DENSE_CAP, doc_base + lo, w.buf_doc,
                                    w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
                 if (round == 0 && hi < n_docs)
@@ -525,7 +579,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             if (rc != SRX_OK) return rc;
             // ---- fallback for queries whose buffer overflowed (degenerate score distributions): through the score
             //      matrix; both kernels return at once unless the any-overflow flag is set ----
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld,
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), THREADS, corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld,
                                (const int *)w.any_ovf);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
@@ -535,7 +589,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
                             (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
             if (rc != SRX_OK) return rc;
         } else {
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), THREADS, corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
@@ -702,3 +756,12 @@ int dense_rows_search(const char *who, int32_t device, const void *rows, const f
     return SRX_OK;
 }
 }  // namespace
+
+#ifdef SRX_DSTAMP
+extern "C" __attribute__((visibility("default"))) int srx_debug_read_dstamps(unsigned long long *h_out16) {
+    HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_dstamp), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dstamp), z, sizeof(z)));
+    return SRX_OK;
+}
+#endif

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sparse_rx
 from oracle import np_oracle
+if os.environ.get("SRX_LIB"):  # dev: an engine variant of tools/build_variant.sh
+    sparse_rx._capi.LIB_PATH = os.path.join(os.path.dirname(sparse_rx._capi.LIB_PATH), os.environ["SRX_LIB"])
 
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 384

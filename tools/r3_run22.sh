@@ -1,7 +1,7 @@
 #!/bin/bash
-# Dev helper (GPU box): round-3 run 21 -- dense INT8: A-fragment reads six deep ahead of the MFMAs
+# Dev helper (GPU box): round-3 run 22 -- dense INT8: eight-wave workgroups on long rows, group-level screen branch
 cd ${GRAFT_REPO_ROOT:-.}
-o=gpurun_out/r3u; mkdir -p $o
+o=gpurun_out/r3v; mkdir -p $o
 export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests/test_dense_int8.py -x -q -m gpu > $o/pytest_dense.log 2>&1; rc=$?; echo "pytest dense rc=$rc"; tail -3 $o/pytest_dense.log
 [ $rc -eq 0 ] || exit $rc
