@@ -94,14 +94,15 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 //
 // Round 3 (the kernel took 1.8 ms per 1 M x 1 024 batch whatever the row length: it waited for one returning global
 // atomic round trip per 32 x 32 tile at two waves per SIMD, and scaled every one of the 10^9 dot products in fp64):
-//  * the query tile's A fragments (KS KiB) are staged through LDS ONCE PER WORKGROUP, double-buffered, by direct
-//    global -> LDS loads (every wave used to read them from L2 itself); beside them a 32-row table {screen, scale, tau};
+//  * the query tile's A fragments (KS KiB) are staged through LDS ONCE PER WORKGROUP, two or three buffers, by direct
+//    global -> LDS loads (every wave used to read them from L2 itself); a table {screen bound, threshold, scale} of all
+//    the pass's queries is built in LDS once per workgroup;
 //  * an fp32 screen decides which accumulator rows need the exact arithmetic at all: with a = fl32(acc) * ds (one rounding;
 //    |acc| < 2^24 is exact in fp32), a score can reach tau only if a >= tau / qs * (1 - 2^-23)(1 - 2^-24) -- the exact chain
 //    fl32(fl64(fl64(acc * qs) * ds)) >= tau needs acc * qs * ds >= tau (1 - 2^-24)(1 - 2^-52)^2 -- and the table holds
 //    fl32(fl32(tau / qs) * (1 - 2^-20)), which is below that (rows whose quotient is not a normal positive number, and
 //    qs <= 0, are not screened).  3 fp32 instructions per accumulator register; the fp64 chain runs for the registers in
-//    which some lane passes (about a third of them at the design point) and decides alone;
+//    which some lane passes (one in ten in the second filter round) and decides alone;
 //  * survivors go to a per-wave LDS list ((query, doc-in-wave), score: 8 bytes) -- wave ballot + mbcnt, no atomics -- and
 //    the list is flushed to the queries' global buffers (one returning atomicAdd per entry, 64 in flight) when half full
 //    and at the end: one global round trip per few hundred survivors instead of one per tile.
@@ -145,8 +146,16 @@ __device__ __forceinline__ void static_for(F &&f) {
         static_for<I + 1, N>(f);
     }
 }
+// (Measured and dropped, profiles/r03_dense_filter_variants.log: eight waves per workgroup on long rows -- half the L2 -> LDS
+// traffic of the query fragments, but one workgroup per CU: its prologue and final flush are dead time -- 3-5 % slower; a
+// ping-pong form of that workgroup -- waves 0-3 and 4-7 half a tile apart, one group in its MFMAs while its SIMD partners
+// screen the tile before, a barrier per phase -- 12-30 % slower: the screening phase (staging issue + screen + wait) is
+// 1.7 x the MFMA phase, and a lock-step pair runs at the pace of the longer one.)
 template <int KS>
-__global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute__((amdgpu_waves_per_eu(2))) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
+constexpr int dense_filter_waves() { return KS > 12 ? SRX_DENSE_NW_LONG : 4; }
+
+template <int KS>
+__global__ __launch_bounds__(64 * dense_filter_waves<KS>()) __attribute__((amdgpu_waves_per_eu(2))) void srx_dense_i8_filter_kernel(const int8_t *__restrict__ corpus,
                                                                        const float *__restrict__ corpus_scale,
                                                                        int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
@@ -158,8 +167,8 @@ __global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute
     // DT doc tiles of 32 per wave: with two, every A fragment (query tile) feeds two MFMAs; the B fragments of both
     // tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
     constexpr int DT = KS <= 12 ? 2 : 1;
-    constexpr int NW = KS > 12 ? SRX_DENSE_NW_LONG : 4;  // waves per workgroup
-    // LDS: two workgroups of four waves per CU must fit (80 KiB each); one of eight waves may take more
+    constexpr int NW = dense_filter_waves<KS>();  // waves per workgroup
+    // LDS: two free-running workgroups of four waves per CU must fit (80 KiB each); one of eight waves may take more
     constexpr int DENSE_CB = KS <= 12 ? 512 : (KS <= 24 ? 256 : 128);  // per-wave survivor list entries
     constexpr int NBUF = (KS <= 16 || NW == 8) ? 3 : 2;  // query tiles in LDS: the one in use and one or two on their way
     constexpr int PD = NBUF - 1;                         // tiles staged ahead
@@ -178,19 +187,18 @@ __global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute
 #endif
     // global -> LDS without a trip through registers (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's
     // LDS base + 16 l): wave w copies the 64-fragment rows w, w + NW, ... of the tile -- EXACTLY ROWS loads per wave and tile
-    // (a wave with a row too many re-copies the tile's last row: same bytes, same place), so that the wait for a tile can be a
-    // counted one: with three buffers the loads of the tile after it stay in flight across the barrier.
+    // (a wave with a row too many re-copies the last row of its share: same bytes, same place), so that the wait for a tile can
+    // be a counted one: the loads of the tile after it stay in flight across the barrier.
     // (Measured and dropped: staging through registers -- global_load_dwordx4 at the top of a tile, ds_write_b128 at its end.
-    // In-kernel stamps put 100-200 cycles on the issue of each staging load either way, ~1 300 cycles per 768-byte-row tile;
-    // the register form was 3 % slower end to end.)
+    // In-kernel stamps put 100-200 cycles on the issue of each staging load either way; the register form was 3 % slower.)
+    auto stage_row = [&](int tile, int buf, int s) __attribute__((always_inline)) {
+        const v4i *src = apack + ((int64_t)tile * KS + s) * 64;  // scalar base + a 32-bit lane offset
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane),
+                                         (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
+    };
     auto stage_tile = [&](int tile, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            const int s = min(wv + row * NW, KS - 1);                    // scalar
-            const v4i *src = apack + ((int64_t)tile * KS + s) * 64;  // scalar base + a 32-bit lane offset
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane),
-                                             (__attribute__((address_space(3))) void *)&ldsA[buf][s * 64], 16, 0, 0);
-        }
+        for (int row = 0; row < ROWS; ++row) stage_row(tile, buf, min(wv + row * NW, KS - 1));
     };
 #pragma unroll
     for (int i = 0; i < PD; ++i)
@@ -243,27 +251,20 @@ __global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute
         cnt = 0;
         dirty = true;
     };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    DSTAMP(0);  // prologue: B fragments, table, first tile staged
-    for (int qt = 0; qt < n_qt; ++qt) {
-        const int q0 = qt * 32;
-        const int cur = qt % NBUF;
-        const bool more = qt + PD < n_qt;                  // uniform
-        if (more) stage_tile(qt + PD, (qt + PD) % NBUF);  // that buffer was last read in tile qt - 1: one barrier ago
-        DSTAMP(1);  // stage issue
-        v16i acc[DT];
+    v16i acc[DT];
+    v4i thb[4];
+    // The MFMAs of query tile `tile` (buffer tile % NBUF).  The tile's 32 screen bounds (rows 8 g + 4 h + 0..3 are accumulator
+    // registers 4 g .. 4 g + 3) and the A fragments are LDS reads issued where they stand, PF of the latter in flight ahead of
+    // the MFMA that consumes them (an LDS read returns after ~100+ cycles, an MFMA issues every 32; the compiler's schedule
+    // reads one ahead and puts each group's bounds right before their use: four more LDS round trips per tile).  LDS reads
+    // return in order, so before step s at most min(PF - 1, KS - 1 - s) younger reads may still be out.
+    auto do_mfma = [&](int tile) __attribute__((always_inline)) {
+        constexpr int PF = KS < SRX_DENSE_PF ? KS : SRX_DENSE_PF;
+        v4i Ab[PF];
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // The tile's 32 screen bounds (rows 8 g + 4 h + 0..3 are accumulator registers 4 g .. 4 g + 3) and the A fragments: LDS
-        // reads issued where they stand, PF of the latter in flight ahead of the MFMA that consumes them (an LDS read returns after
-        // ~100+ cycles, an MFMA issues every 32; the compiler's schedule reads one ahead and puts each group's bounds right before
-        // their use: four more LDS round trips per tile).  LDS reads return in order, so before step s at most
-        // min(PF - 1, KS - 1 - s) younger reads may still be out.
-        constexpr int PF = KS < SRX_DENSE_PF ? KS : SRX_DENSE_PF;
-        v4i Ab[PF], thb[4];
-        const unsigned a_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&ldsA[cur][lane];
-        const unsigned t_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&tab.thr[q0 + 4 * h];
+        const unsigned a_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&ldsA[tile % NBUF][lane];
+        const unsigned t_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&tab.thr[tile * 32 + 4 * h];
         static_for<0, 4>([&](auto g) { lds_read128<decltype(g)::value * 32>(thb[decltype(g)::value], t_addr); });
         static_for<0, PF>([&](auto i) { lds_read128<decltype(i)::value * 1024>(Ab[decltype(i)::value], a_addr); });
         static_for<0, KS>([&](auto i) {
@@ -273,19 +274,33 @@ __global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute
             for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ab[s % PF], B[t][s], acc[t], 0, 0, 0);
             if constexpr (s + PF < KS) lds_read128<(s + PF) * 1024>(Ab[s % PF], a_addr);
         });
-        DSTAMP(2);  // MFMA loop (to the issue of the last one)
+    };
+    // Screen + exact arithmetic + survivor list of the tile in acc / thb
+    auto do_epilogue = [&](int tile) __attribute__((always_inline)) {
+        const int q0 = tile * 32;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const double ds = (double)dsf[t];
+            // all 16 screens first: independent instructions, one vector-to-scalar round trip and one branch for the whole tile
+            // when nothing passes (a branch per group of four put four such round trips in a row).  "not below" instead of ">=":
+            // a NaN (0 * inf, a NaN scale) goes to the exact arithmetic too
+            unsigned long long mka[16];  // lane masks in scalar registers: v_cmp writes them, s_or combines them
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // "not below" instead of ">=": a NaN (0 * inf, a NaN scale) goes to the exact arithmetic too
                 const float thv[4] = {__int_as_float(thb[g].x), __int_as_float(thb[g].y), __int_as_float(thb[g].z), __int_as_float(thb[g].w)};
-                unsigned long long mk[4];  // lane masks in scalar registers: v_cmp writes them, s_or combines them
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mk[j] = __ballot(!((float)acc[t][4 * g + j] * dsf[t] < thv[j]));
+                for (int j = 0; j < 4; ++j) mka[4 * g + j] = __ballot(!((float)acc[t][4 * g + j] * dsf[t] < thv[j]));
+            }
+            unsigned long long many = 0ull;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) many |= mka[i];
+            if (many == 0ull) continue;  // uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float thv[4] = {__int_as_float(thb[g].x), __int_as_float(thb[g].y), __int_as_float(thb[g].z), __int_as_float(thb[g].w)};
+                const unsigned long long mk[4] = {mka[4 * g], mka[4 * g + 1], mka[4 * g + 2], mka[4 * g + 3]};
                 if ((mk[0] | mk[1] | mk[2] | mk[3]) == 0ull) continue;  // uniform: most groups of four end here
-                // the rows' thresholds and fp64 scales, read once per group (a read inside every exact branch put two LDS round
+                // the rows' thresholds and scales, read once per group (a read inside every exact branch put two LDS round
                 // trips into each of them, at two waves per SIMD)
                 const uint4 ta = *reinterpret_cast<const uint4 *>(&tab.tau[q0 + 8 * g + 4 * h]);
                 const float4 qa = *reinterpret_cast<const float4 *>(&tab.qs[q0 + 8 * g + 4 * h]);
@@ -324,17 +339,31 @@ __global__ __launch_bounds__(KS > 12 ? 64 * SRX_DENSE_NW_LONG : 256) __attribute
                 }
             }
         }
+    };
+    // A bare s_barrier: __syncthreads() puts s_waitcnt vmcnt(0) in front of it, which would wait for the staging loads that are
+    // meant to stay in flight.  Every wave has waited (counted) for its own share of the tile that the barrier publishes.
+    auto phase_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DSTAMP(0);  // prologue: B fragments, table, first tiles staged
+    for (int qt = 0; qt < n_qt; ++qt) {
+        const bool more = qt + PD < n_qt;                  // uniform
+        if (more) stage_tile(qt + PD, (qt + PD) % NBUF);  // that buffer was last read in tile qt - 1: one barrier ago
+        DSTAMP(1);  // stage issue
+        do_mfma(qt);
+        DSTAMP(2);  // MFMA loop (to the issue of the last one)
+        do_epilogue(qt);
         DSTAMP(3);  // epilogue (waits for the accumulators first)
         if (cnt >= DENSE_CB / 2) flush();  // uniform
-        // my share of tile qt + 1 has landed (with three buffers it was issued a whole tile ago, and the loads of tile qt + 2 stay
-        // in flight).  Loads return in order; stores / atomics of mine (a flush) may not, so after one everything is drained.
+        // my share of tile qt + 1 has landed (with three buffers it was issued a whole tile ago, and the loads of tile qt + 2
+        // stay in flight).  Loads return in order; stores / atomics of mine (a flush) may not, so after one everything is drained.
         if (PD > 1 && more && !dirty)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * ROWS) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dirty = false;
         DSTAMP(4);  // flush, wait for the staged tile
-        __syncthreads();  // every wave's share of tile qt + 1 is in LDS; tile qt's buffer is free
+        phase_barrier();  // every wave's share of tile qt + 1 is in LDS; tile qt's buffer is free
         DSTAMP(5);  // barrier
     }
     if (cnt > 0) flush();
@@ -553,10 +582,12 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             // the docs [0, S1), S1 = sqrt(S n), the k-th best of its survivors (a valid lower bound too, and never below the
             // sample's) is the threshold of the second round over [S1, n): about k (S1 / S + n / S1) survivors per query instead
             // of k n / S -- 4x fewer exact-path rows and buffer appends at 1 M docs.  Both rounds append to the same buffers.
-            const int filter_threads = dim / 32 > 12 ? 64 * SRX_DENSE_NW_LONG : 256;  // srx_dense_i8_filter_kernel: eight waves per workgroup on long rows
-            const int64_t docs_per_block = dim / 32 <= 12 ? 64 * 4 : 32 * SRX_DENSE_NW_LONG;
+            const int ks = dim / 32;
+            const int filter_waves = ks > 12 ? SRX_DENSE_NW_LONG : 4;  // = dense_filter_waves<KS>()
+            const int filter_threads = 64 * filter_waves;
+            const int64_t docs_per_block = (ks <= 12 ? 64 : 32) * filter_waves;
             int64_t S1 = (int64_t)sqrt((double)S * (double)n_docs);
-            const int64_t chip = docs_per_block * (dim / 32 > 12 ? 2048 / SRX_DENSE_NW_LONG : 512);  // whole rounds of the chip (8 waves per CU)
+            const int64_t chip = docs_per_block * (2048 / filter_waves);  // whole rounds of the chip at eight waves per CU
             S1 = S1 >= chip ? (S1 + chip - 1) / chip * chip : (S1 + docs_per_block - 1) / docs_per_block * docs_per_block;
             if (S1 * 2 > n_docs) S1 = n_docs;  // small corpus: one round
             for (int round = 0; round < 2; ++round) {
