@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 300 /* 0.3.0: + srx_search_after (ranking of any depth) */
+#define SRX_VERSION 301 /* 0.3.1: + srx_search_after (ranking of any depth), srx_build_term_bounds */
 
 typedef enum {
     SRX_OK = 0,
@@ -235,6 +235,15 @@ int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, 
                      const int32_t *post_doc, const void *post_val, const int32_t *skip, const int64_t *runpad,
                      int64_t vocab, int64_t nnz, int32_t n_tiles, int32_t tile_log2, int32_t unit_tiles, int32_t *out_post,
                      int32_t *out_skip, int64_t *out_term_ptr, int64_t n_blocks, void *stream);
+
+/* Per-term score bounds (srx_index_desc.term_bound and the finer table the sharded build combines): out_bound[t * nk + j] =
+ * the ks[j]-th largest value of term t's run post_val[term_ptr[t] .. term_ptr[t + 1]) of the term-major value array (before
+ * blocking; f32 or f16 by val_type), 0 where the term has fewer than ks[j] positive values.  ks i32[nk] on the device,
+ * 1 <= ks[j] <= 1024, nk <= 64.  *neg_flag (device i32) is set to 1 when a value is negative: the bounds must then not be
+ * used.  One streaming pass (the selection machinery of the search kernels); replaces no reference code: the reference has
+ * no score bounds. */
+int srx_build_term_bounds(int32_t device, int32_t val_type, const int64_t *term_ptr, const void *post_val, int64_t vocab,
+                          const int32_t *ks, int32_t nk, float *out_bound, int32_t *neg_flag, void *stream);
 
 /* Compact copy of the blocks for the tier-1 kernel (replaces nothing in the reference: a storage choice of this engine).
  * Block b of `post` (n_blocks_total = n_blocks + SRX_BLOCK_PAD of them) becomes

@@ -76,6 +76,7 @@ SYMBOLS = {
     "srx_auto_unit_tiles": (_I32, [_I64, _I64, _I64, _I32]),
     "srx_build_blocks": (ctypes.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_compact": (ctypes.c_int, [_I32, _I32, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "srx_build_term_bounds": (ctypes.c_int, [_I32, _I32, _VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
 }
 

@@ -1969,6 +1969,96 @@ SRX_API int srx_build_impacts(int32_t device, const float *tf, const int32_t *po
     return SRX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Term bounds: out[t * nk + j] = the ks[j]-th largest stored value of term t (0 when it has fewer than ks[j] positive
+// values).  One workgroup per term (grid-stride): the term's run of the term-major value array is folded into the
+// exact lazy top-k list of the search kernels (k = the largest rank asked for, <= 1 024), then every kept value counts
+// the kept values above it and equal to it and writes the ranks it covers.  One streaming pass over the values; the
+// first form was a 64-bit sort of (term, value) keys of ALL postings (16+ bytes of temporary memory per posting, the
+// build's peak).  A negative value raises *neg_flag (the bounds are only valid for non-negative values).
+namespace {
+constexpr int TB_NPT = 16;
+template <typename VT>
+__global__ __launch_bounds__(THREADS) void srx_term_bounds_kernel(const int64_t *__restrict__ term_ptr, const VT *__restrict__ val,
+                                                                  int64_t vocab, const int32_t *__restrict__ ks, int nk, int kmax,
+                                                                  float *__restrict__ out, int *__restrict__ neg_flag) {
+    __shared__ MergeShared M;
+    const int tid = threadIdx.x;
+    for (int64_t t = blockIdx.x; t < vocab; t += gridDim.x) {
+        const int64_t lo = term_ptr[t], hi = term_ptr[t + 1];
+        if (tid < nk) out[t * nk + tid] = 0.0f;
+        if (tid == 0) {
+            M.tk.count = 0;
+            M.tk.tau = 0;
+        }
+        __syncthreads();
+        bool neg = false;
+        for (int64_t c0 = lo; c0 < hi; c0 += (int64_t)THREADS * TB_NPT) {
+            unsigned ubits[TB_NPT];
+            int udoc[TB_NPT];
+            const unsigned tau = M.tk.tau;
+#pragma unroll
+            for (int n = 0; n < TB_NPT; ++n) {
+                const int64_t c = c0 + (int64_t)n * THREADS + tid;
+                float x = 0.0f;
+                if (c < hi) x = (float)val[c];
+                neg |= x < 0.0f;
+                const unsigned b = __float_as_uint(x);
+                ubits[n] = (x > 0.0f && b >= tau) ? b : 0u;
+                udoc[n] = (int)(c - lo);
+            }
+            topk_fold<TB_NPT, true>(ubits, udoc, kmax, M.tk, M.hist);
+        }
+        if (neg) *neg_flag = 1;
+        __syncthreads();
+        topk_shrink(kmax, M.tk, M.hist);
+        __syncthreads();
+        const unsigned cnt = M.tk.count;
+        for (unsigned i = tid; i < cnt; i += THREADS) {
+            const unsigned xi = M.tk.bits[i];
+            int gt = 0, eq = 0;
+            for (unsigned j = 0; j < cnt; ++j) {  // every thread reads the same word: an LDS broadcast
+                const unsigned xj = M.tk.bits[j];
+                gt += xj > xi;
+                eq += xj == xi;
+            }
+            for (int j = 0; j < nk; ++j) {
+                const int K = ks[j];
+                if (gt < K && K <= gt + eq) out[t * nk + j] = __uint_as_float(xi);  // ties write the same value
+            }
+        }
+        __syncthreads();  // the list is re-initialised by the next term
+    }
+}
+}  // namespace
+
+SRX_API int srx_build_term_bounds(int32_t device, int32_t val_type, const int64_t *term_ptr, const void *post_val, int64_t vocab,
+                                  const int32_t *ks, int32_t nk, float *out_bound, int32_t *neg_flag, void *stream_v) {
+    if (!term_ptr || !post_val || !ks || !out_bound || !neg_flag || vocab <= 0 || nk <= 0 || nk > 64)
+        return fail(SRX_ERR_INVALID, "srx_build_term_bounds: bad argument (1 <= nk <= 64)%s");
+    if (val_type != SRX_VAL_F32 && val_type != SRX_VAL_F16) return fail(SRX_ERR_INVALID, "srx_build_term_bounds: unknown val_type%s");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    int32_t hks[64];
+    HIP_TRY(hipMemcpyAsync(hks, ks, sizeof(int32_t) * nk, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    int kmax = 0;
+    for (int j = 0; j < nk; ++j) {
+        if (hks[j] < 1 || hks[j] > KMAX) return fail(SRX_ERR_INVALID, "srx_build_term_bounds: ranks must be in 1 .. 1024%s");
+        if (hks[j] > kmax) kmax = hks[j];
+    }
+    HIP_TRY(hipMemsetAsync(neg_flag, 0, sizeof(int32_t), stream));
+    const unsigned blocks = (unsigned)(vocab < 256 * 16 ? vocab : 256 * 16);
+    if (val_type == SRX_VAL_F32)
+        hipLaunchKernelGGL(srx_term_bounds_kernel<float>, dim3(blocks), dim3(THREADS), 0, stream, term_ptr, (const float *)post_val, vocab,
+                           ks, (int)nk, kmax, out_bound, (int *)neg_flag);
+    else
+        hipLaunchKernelGGL(srx_term_bounds_kernel<__half>, dim3(blocks), dim3(THREADS), 0, stream, term_ptr, (const __half *)post_val,
+                           vocab, ks, (int)nk, kmax, out_bound, (int *)neg_flag);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
+}
+
 SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *post_doc, int64_t vocab,
                                 int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream_v) {
     if (!term_ptr || !out_skip || vocab <= 0 || n_tiles <= 0 || tile_log2 < 0 || tile_log2 > 30)

@@ -395,25 +395,23 @@ class DeviceIndex:
 
     @staticmethod
     def _term_bounds(torch, cols_sorted, post_val, term_ptr, df, V):
-        """out[t, j] = the K_j-th largest stored value of term t for K_j in FINE_KS (0 if it has fewer than K_j
-        postings), or None when some value is negative.  One sort of (term, value descending) keys; exact."""
+        """out[t, j] = the K_j-th largest stored value of term t for K_j in FINE_KS (0 if it has fewer than K_j positive
+        values), or None when some value is negative.  ``srx_build_term_bounds``: one streaming pass over the term-major
+        values (post_val f32 / f16, term_ptr the unpadded run starts); exact."""
         nnz = post_val.numel()
         if nnz == 0 or cols_sorted is None:
             return None
-        v32 = post_val.float()
-        if float(v32.min()) < 0.0:
+        dev = post_val.device
+        ks = torch.tensor(DeviceIndex.FINE_KS, dtype=torch.int32, device=dev)
+        out = torch.empty((V, len(DeviceIndex.FINE_KS)), dtype=torch.float32, device=dev)
+        neg = torch.zeros(1, dtype=torch.int32, device=dev)
+        val_type = _capi.SRX_VAL_F16 if post_val.dtype == torch.float16 else _capi.SRX_VAL_F32
+        _capi.check(_capi.lib().srx_build_term_bounds(dev.index or 0, val_type, _ptr(term_ptr), _ptr(post_val.contiguous()), V, _ptr(ks),
+                                                      len(DeviceIndex.FINE_KS), _ptr(out), _ptr(neg), _stream_ptr(torch, dev)),
+                    "srx_build_term_bounds")
+        if int(neg.item()) != 0:
             return None
-        bits = v32.view(torch.int32).to(torch.int64)  # non-negative floats: integer order == value order
-        key = (cols_sorted.to(torch.int64) << 32) | (0xFFFFFFFF - bits)
-        del bits, v32
-        key = torch.sort(key).values
-        out = torch.zeros((V, len(DeviceIndex.FINE_KS)), dtype=torch.float32, device=post_val.device)
-        for j, K in enumerate(DeviceIndex.FINE_KS):
-            has = df >= K
-            pos = (term_ptr[:-1] + (K - 1)).clamp(max=nnz - 1)
-            b = (0xFFFFFFFF - (key[pos] & 0xFFFFFFFF)).to(torch.int32).view(torch.float32)
-            out[:, j] = torch.where(has, b, torch.zeros_like(b))
-        return out.contiguous()
+        return out
 
     @classmethod
     def from_host_index(cls, hi: HostIndex, k1: float = 1.2, b: float = 0.75, **kw) -> "DeviceIndex":

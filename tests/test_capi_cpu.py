@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libsparse_rx.so does not export {name}"
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
-    assert L.srx_version() == 300
+    assert L.srx_version() == 301
 
 
 def test_limits_and_error_strings():
@@ -36,6 +36,9 @@ def test_limits_and_error_strings():
     assert L.srx_build_compact(0, 0, None, 10, 14, 3, None, None) == -1 and b"srx_build_compact" in L.srx_last_error()
     assert L.srx_build_compact(0, 0, 1 << 20, 10, 14, 4, 1 << 21, None) == -1 and b"49152" in L.srx_last_error()   # 4 x 16384 docs per unit
     assert L.srx_build_compact(0, 7, 1 << 20, 10, 14, 3, 1 << 21, None) == -1 and b"val_type" in L.srx_last_error()
+    assert L.srx_build_term_bounds(0, 0, None, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"srx_build_term_bounds" in L.srx_last_error()
+    assert L.srx_build_term_bounds(0, 0, 1 << 19, 1 << 20, 10, 1 << 21, 65, 1 << 22, 1 << 23, None) == -1 and b"nk" in L.srx_last_error()
+    assert L.srx_build_term_bounds(0, 7, 1 << 19, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"val_type" in L.srx_last_error()
     assert L.srx_dense_search_u8(0, 1 << 20, None, 10, 64, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1
     assert L.srx_dense_search_u8(0, 1 << 20, 1 << 26, 10, 48, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1
     assert b"multiple of 64" in L.srx_last_error()

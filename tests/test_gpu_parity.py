@@ -376,6 +376,43 @@ def test_merge_topk_matches_single_shard(rx):
         ix.close()
 
 
+def test_term_bounds_kernel_matches_sorted_values(rx):
+    """srx_build_term_bounds (the K-th largest stored value of every term for K in FINE_KS, through DeviceIndex._term_bounds)
+    against a NumPy sort of every term's values: ties at the ranks, zeros (they do not count: a bound of 0 either way), empty
+    terms, terms shorter and longer than 1 024 postings and longer than one pass of the kernel (4 096), f32 and f16; a negative
+    value anywhere -> no bounds."""
+    import torch
+    rng = np.random.default_rng(31)
+    lens = np.concatenate([[0, 1, 2, 9, 10, 11, 99, 100, 101, 1000, 1023, 1024, 1025, 4096, 4097, 20_000, 150_000, 0, 3],
+                           rng.integers(0, 300, 400)]).astype(np.int64)
+    V = len(lens)
+    term_ptr = np.zeros(V + 1, np.int64)
+    term_ptr[1:] = np.cumsum(lens)
+    nnz = int(term_ptr[-1])
+    for dt in (np.float32, np.float16):
+        vals = rng.random(nnz).astype(np.float32)
+        vals[rng.random(nnz) < 0.2] = 0.0
+        few = rng.random(nnz) < 0.3
+        vals[few] = rng.choice(np.array([0.25, 0.5, 0.75, 1.5], np.float32), int(few.sum()))  # heavy ties
+        vals = vals.astype(dt)
+        dev = torch.device("cuda:0")
+        tp_d = torch.as_tensor(term_ptr, device=dev)
+        v_d = torch.as_tensor(vals, device=dev)
+        cols = torch.zeros(1, dtype=torch.int32, device=dev)  # only tested for None-ness
+        got = rx.DeviceIndex._term_bounds(torch, cols, v_d, tp_d, None, V).cpu().numpy()
+        ks = rx.DeviceIndex.FINE_KS
+        exp = np.zeros((V, len(ks)), np.float32)
+        for t in range(V):
+            x = np.sort(vals[term_ptr[t]:term_ptr[t + 1]].astype(np.float32))[::-1]
+            for j, K in enumerate(ks):
+                if K <= len(x):
+                    exp[t, j] = x[K - 1]
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), dt
+        v_neg = v_d.clone()
+        v_neg[nnz // 2] = -0.5
+        assert rx.DeviceIndex._term_bounds(torch, cols, v_neg, tp_d, None, V) is None
+
+
 def test_blocked_layout_matches_numpy_builder(rx):
     """srx_build_tile_skip + srx_build_blocks (device index construction) against the NumPy restatement of the blocked
     layout (tests/parity.py): padded runs per unit, sentinels (doc -1, value 0), padded skip table and term offsets --
