@@ -473,6 +473,10 @@ int dense_splits(int64_t n_docs, int nq, int k) {
 int64_t dense_sample(int64_t n_docs, int k) {
     int64_t S = (8 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
     if (S < 16384) S = 16384;
+#ifdef SRX_DENSE_KNOBS  // dev build: scale the sample (tools/r3_run33.sh)
+    if (const char *e = getenv("SRX_DENSE_SAMPLE_MULT")) S = (int64_t)((double)S * atof(e));
+    if (S < 2048) S = 2048;
+#endif
     S = (S + 127) / 128 * 128;
     return (S * 4 <= n_docs) ? S : 0;
 }
