@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 301 /* 0.3.1: + srx_search_after (ranking of any depth), srx_build_term_bounds */
+#define SRX_VERSION 301 /* 0.3.1: + srx_search_after (ranking of any depth), srx_build_term_bounds, packed dense corpus */
 
 typedef enum {
     SRX_OK = 0,
@@ -272,6 +272,18 @@ int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpu
                         const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
                         int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace, int64_t workspace_bytes,
                         void *stream);
+/* The same search on a corpus kept in MFMA-fragment order (what the retriever keeps resident instead of the row-major
+ * matrix the reference holds, retriever_registry.py:389-392: a storage choice of this engine, same bytes): for tile
+ * T = 32 rows, k-step s (32 columns) and lane l the 16 bytes rows[32 T + (l & 31)][32 s + 16 (l >> 5) ..] sit at
+ * packed + ((T * dim / 32 + s) * 64 + l) * 16; rows past n_rows are zeros.  A wave's B-fragment load is then one contiguous
+ * KiB instead of a load that touches 32 rows.  srx_dense_packed_bytes = the size of that buffer; srx_dense_pack_i8
+ * builds it from the row-major matrix (16-byte aligned device pointers).  Results are identical to srx_dense_search_i8. */
+int64_t srx_dense_packed_bytes(int64_t n_rows, int32_t dim);
+int srx_dense_pack_i8(int32_t device, const int8_t *rows, int64_t n_rows, int32_t dim, void *out_packed, void *stream);
+int srx_dense_search_i8_packed(int32_t device, const void *corpus_packed, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                               const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                               int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                               int64_t workspace_bytes, void *stream);
 
 /* Dense f32 side: replaces np.dot(embedding_index, query_vector) + the top-k after it in
  * RetrievalService.search_by_vector (rag_system/core/retrieval.py:411-423).  emb f32[n_docs][dim], queries f32[nq][dim],

@@ -67,6 +67,9 @@ SYMBOLS = {
     "srx_merge_topk_packed_out": (ctypes.c_int, [_I32, _VP, _I32, _I32, _I32, _VP, _VP, _I64, _VP]),
     "srx_dense_workspace_bytes": (_I64, [_I32, _I64, _I32]),
     "srx_dense_search_i8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "srx_dense_packed_bytes": (_I64, [_I64, _I32]),
+    "srx_dense_pack_i8": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _VP]),
+    "srx_dense_search_i8_packed": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "srx_dense_f32_workspace_bytes": (_I64, [_I32, _I64, _I32]),
     "srx_dense_search_f32": (ctypes.c_int, [_I32, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP, ctypes.c_float]),
     "srx_dense_search_u8": (ctypes.c_int, [_I32, _VP, _VP, _I64, _I32, _VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),

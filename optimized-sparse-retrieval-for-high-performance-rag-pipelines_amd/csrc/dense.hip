@@ -24,17 +24,19 @@ constexpr int DENSE_CNT_STRIDE = 32;  // ints between two queries' candidate cou
 // Query batch in MFMA-fragment order: apack[(tile * KS + s) * 64 + lane] = the 16 bytes lane `lane` feeds into k-step s
 // of query tile `tile` (row tile * 32 + (lane & 31), columns 32 s + 16 (lane >> 5) ..).  A wave's A load is then one
 // contiguous 1 KiB block instead of 32 scattered 32-byte segments (the request rate of the texture path was the limit).
-__global__ __launch_bounds__(THREADS) void srx_dense_pack_queries_kernel(const int8_t *__restrict__ queries, int nq, int dim,
+// The corpus can be kept in the same order (srx_dense_pack_i8: tile = 32 docs): a wave's B fragments are then KS contiguous
+// 1 KiB loads instead of KS loads that each touch 32 rows.
+__global__ __launch_bounds__(THREADS) void srx_dense_pack_queries_kernel(const int8_t *__restrict__ queries, int64_t nq, int dim,
                                                                          v4i *__restrict__ apack) {
     const int ks = dim / 32;
-    const int64_t n = (int64_t)((nq + 31) / 32) * ks * 64;
+    const int64_t n = ((nq + 31) / 32) * ks * 64;
     for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
         const int lane = (int)(i & 63);
         const int64_t ts = i >> 6;
         const int s = (int)(ts % ks);
-        const int q = (int)(ts / ks) * 32 + (lane & 31);
+        const int64_t q = (ts / ks) * 32 + (lane & 31);
         v4i x = {0, 0, 0, 0};
-        if (q < nq) x = *reinterpret_cast<const v4i *>(queries + (int64_t)q * dim + s * 32 + 16 * (lane >> 5));
+        if (q < nq) x = *reinterpret_cast<const v4i *>(queries + q * dim + s * 32 + 16 * (lane >> 5));
         apack[i] = x;
     }
 }
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
                                                                        int64_t n_docs, const v4i *__restrict__ apack,
                                                                        const float *__restrict__ query_scale, int nq,
                                                                        float *__restrict__ scores, int64_t ld,
-                                                                       const int *__restrict__ gate) {
+                                                                       const int *__restrict__ gate, int packed) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t d0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 32;
     if (d0 >= n_docs) return;
@@ -61,7 +63,10 @@ __global__ __launch_bounds__(THREADS) void srx_dense_i8_scores_kernel(const int8
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         B[s] = (v4i){0, 0, 0, 0};
-        if (dok) B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+        if (packed)  // uniform: fragment order, rows past the corpus are zeros there
+            B[s] = reinterpret_cast<const v4i *>(corpus)[((d0 >> 5) * KS + s) * 64 + lane];
+        else if (dok)
+            B[s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
     }
     const double ds = dok ? (double)corpus_scale[d] : 0.0;
     // gridDim.y splits the query tiles (the threshold sample is a few hundred workgroups of docs only: the split fills the chip)
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * dense_filter_waves<KS>()) __attribute__((amdgp
                                                                        int64_t doc_base, int32_t *__restrict__ buf_doc,
                                                                        float *__restrict__ buf_score,
                                                                        int *__restrict__ buf_cnt, int *__restrict__ ovf,
-                                                                       int *__restrict__ any_ovf) {
+                                                                       int *__restrict__ any_ovf, int packed) {
     // DT doc tiles of 32 per wave: with two, every A fragment (query tile) feeds two MFMAs; the B fragments of both
     // tiles must fit the register file (KS <= 12, i.e. rows up to 384 bytes).
     constexpr int DT = KS <= 12 ? 2 : 1;
@@ -229,7 +234,11 @@ __global__ __launch_bounds__(64 * dense_filter_waves<KS>()) __attribute__((amdgp
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             B[t][s] = (v4i){0, 0, 0, 0};
-            if (dok) B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+            if (packed) {  // uniform: fragment order (srx_dense_pack_i8), one contiguous KiB per load; rows past the corpus are zeros
+                if (d0 + 32 * t < n_docs) B[t][s] = reinterpret_cast<const v4i *>(corpus)[(((d0 >> 5) + t) * KS + s) * 64 + lane];
+            } else if (dok) {
+                B[t][s] = *reinterpret_cast<const v4i *>(corpus + d * DIM + s * 32 + 16 * h);
+            }
         }
         dsf[t] = dok ? corpus_scale[d] : 0.0f;  // 0: every score of a row past the corpus is 0 or NaN, never > 0
     }
@@ -468,10 +477,12 @@ int dense_splits(int64_t n_docs, int nq, int k) {
     if (s < 1) s = 1;
     return (int)s;
 }
-// Sample size of the threshold pass: the k-th best score of S docs leaves about k * n_docs / S survivors per query;
-// aim at DENSE_CAP / 8.  0 = corpus too small for the filtered path to pay.
+// Sample size of the threshold pass: the k-th best score of S docs leaves about k * n_docs / S survivors per query in one
+// filter round (aim: DENSE_CAP / 3), 2 k sqrt(n_docs / S) in two.  The sample goes through the score matrix, so it should
+// be small: swept in profiles/r03_dense_filter_variants.log (k = 1 000: 2.51 ms at 8 k n / CAP, 2.19-2.22 ms at 2-4 k n / CAP).
+// 0 = corpus too small for the filtered path to pay.
 int64_t dense_sample(int64_t n_docs, int k) {
-    int64_t S = (8 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
+    int64_t S = (3 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
     if (S < 16384) S = 16384;
 #ifdef SRX_DENSE_KNOBS  // dev build: scale the sample (tools/r3_run33.sh)
     if (const char *e = getenv("SRX_DENSE_SAMPLE_MULT")) S = (int64_t)((double)S * atof(e));
@@ -526,10 +537,11 @@ SRX_API int64_t srx_dense_workspace_bytes(int32_t nq, int64_t n_docs, int32_t k)
     return dense_ws(nullptr, nq, n_docs, k).bytes;
 }
 
-SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
-                                const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
-                                int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
-                                int64_t workspace_bytes, void *stream_v) {
+namespace {
+int dense_search_i8_impl(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                         const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                         int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace, int64_t workspace_bytes,
+                         void *stream_v, int packed) {
     if (nq < 0 || n_docs <= 0 || k <= 0 || k > KMAX) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: need n_docs > 0, 1 <= k <= 1024%s");
     if (dim <= 0 || dim % 32 != 0 || dim > 1024)
         return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be a multiple of 32, <= 1024 (pad the rows with zeros)%s");
@@ -573,11 +585,11 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
         float *os = out_score + (int64_t)q0 * k;
         int32_t *oc = out_count + q0;
         const int *no_gate = nullptr;
-        hipLaunchKernelGGL(srx_dense_pack_queries_kernel, dim3(64), dim3(THREADS), 0, stream, qp, qb, (int)dim, w.apack);
+        hipLaunchKernelGGL(srx_dense_pack_queries_kernel, dim3(64), dim3(THREADS), 0, stream, qp, (int64_t)qb, (int)dim, w.apack);
         if (S > 0) {
             // ---- filtered path: threshold from a sample, GEMM with the filter fused in, rank the candidate buffers ----
             HIP_TRY(hipMemsetAsync(w.buf_cnt, 0, (size_t)(qbmax * DENSE_CNT_STRIDE + qbmax + 1) * 4, stream));
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, dim3(blocks_for(S), (unsigned)((qb + 127) / 128)), THREADS, corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, dim3(blocks_for(S), (unsigned)((qb + 127) / 128)), THREADS, corpus, corpus_scale, S, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate, packed);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.scores, ld, S, qb, k, 1, doc_base,
                                0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate, w.cand_doc,
@@ -599,7 +611,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
                 if (lo >= hi) break;
                 SRX_DENSE_DISPATCH(srx_dense_i8_filter_kernel, (unsigned)((hi - lo + docs_per_block - 1) / docs_per_block), filter_threads, corpus + lo * dim,
                                    corpus_scale + lo, hi - lo, (const v4i *)w.apack, qs, qb, w.tau, DENSE_CAP, doc_base + lo, w.buf_doc,
-                                   w.buf_score, w.buf_cnt, w.ovf, w.any_ovf);
+                                   w.buf_score, w.buf_cnt, w.ovf, w.any_ovf, packed);
                 if (round == 0 && hi < n_docs)
                     hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)qb), dim3(THREADS), 0, stream, w.buf_score, (int64_t)DENSE_CAP,
                                        n_docs, qb, k, 1, doc_base, 1, w.buf_doc, w.buf_cnt, DENSE_CAP, (const int *)nullptr, 0, no_gate,
@@ -615,7 +627,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
             // ---- fallback for queries whose buffer overflowed (degenerate score distributions): through the score
             //      matrix; both kernels return at once unless the any-overflow flag is set ----
             SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), THREADS, corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld,
-                               (const int *)w.any_ovf);
+                               (const int *)w.any_ovf, packed);
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)w.ovf, 1,
                                (const int *)w.any_ovf, w.cand_doc, w.cand_score, w.cand_count, (unsigned *)nullptr, 0);
@@ -624,7 +636,7 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
                             (int64_t)k, (int64_t)1, nullptr, 0, stream_v, (const int *)w.any_ovf);
             if (rc != SRX_OK) return rc;
         } else {
-            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), THREADS, corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate);
+            SRX_DENSE_DISPATCH(srx_dense_i8_scores_kernel, blocks_for(n_docs), THREADS, corpus, corpus_scale, n_docs, (const v4i *)w.apack, qs, qb, w.scores, ld, no_gate, packed);
             if (!ks_ok) break;
             hipLaunchKernelGGL(srx_dense_topk_kernel, dim3((unsigned)((int64_t)qb * ns)), dim3(THREADS), 0, stream, w.scores, ld, n_docs,
                                qb, k, ns, doc_base, 0, (const int32_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, 0, no_gate,
@@ -637,6 +649,39 @@ SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const floa
     }
 #undef SRX_DENSE_DISPATCH
     if (!ks_ok) return fail(SRX_ERR_INVALID, "srx_dense_search_i8: dim must be 32, 64, 96, 128, 192, 256, 384, 512, 768 or 1024 (pad the rows with zeros)%s");
+    return SRX_OK;
+}
+}  // namespace
+
+SRX_API int srx_dense_search_i8(int32_t device, const int8_t *corpus, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                                const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                                int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                                int64_t workspace_bytes, void *stream_v) {
+    return dense_search_i8_impl(device, corpus, corpus_scale, n_docs, dim, queries, query_scale, nq, k, doc_base, out_doc, out_score,
+                                out_count, workspace, workspace_bytes, stream_v, 0);
+}
+
+SRX_API int srx_dense_search_i8_packed(int32_t device, const void *corpus_packed, const float *corpus_scale, int64_t n_docs, int32_t dim,
+                                       const int8_t *queries, const float *query_scale, int32_t nq, int32_t k, int64_t doc_base,
+                                       int32_t *out_doc, float *out_score, int32_t *out_count, void *workspace,
+                                       int64_t workspace_bytes, void *stream_v) {
+    return dense_search_i8_impl(device, (const int8_t *)corpus_packed, corpus_scale, n_docs, dim, queries, query_scale, nq, k, doc_base,
+                                out_doc, out_score, out_count, workspace, workspace_bytes, stream_v, 1);
+}
+
+SRX_API int64_t srx_dense_packed_bytes(int64_t n_rows, int32_t dim) {
+    if (n_rows < 0 || dim <= 0 || dim % 32 != 0 || dim > 1024) return fail(SRX_ERR_INVALID, "srx_dense_packed_bytes: bad argument%s");
+    return (n_rows + 31) / 32 * 32 * (int64_t)dim;
+}
+
+SRX_API int srx_dense_pack_i8(int32_t device, const int8_t *rows, int64_t n_rows, int32_t dim, void *out_packed, void *stream_v) {
+    if (n_rows <= 0 || dim <= 0 || dim % 32 != 0 || dim > 1024 || !rows || !out_packed)
+        return fail(SRX_ERR_INVALID, "srx_dense_pack_i8: need rows, n_rows > 0, dim a multiple of 32 <= 1024%s");
+    if (((uintptr_t)rows | (uintptr_t)out_packed) & 15) return fail(SRX_ERR_INVALID, "srx_dense_pack_i8: rows / out_packed must be 16-byte aligned%s");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(srx_dense_pack_queries_kernel, dim3(4096), dim3(THREADS), 0, (hipStream_t)stream_v, rows, n_rows, (int)dim,
+                       (v4i *)out_packed);
+    HIP_TRY(hipGetLastError());
     return SRX_OK;
 }
 

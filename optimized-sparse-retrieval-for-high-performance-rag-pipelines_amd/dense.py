@@ -65,9 +65,10 @@ def _pad_dim(dim: int) -> int:
 class DenseInt8Index:
     """INT8 corpus resident in HBM: ``corpus_int8`` i8[n_docs, dim] (rows zero-padded to a supported length) and
     ``corpus_scales`` f32[n_docs] -- the state ``QuantizedEmbeddingRetriever.build_index_from_corpus`` keeps
-    (retriever_registry.py:389-392)."""
+    (retriever_registry.py:389-392).  By default the matrix is kept in MFMA-fragment order only (``srx_dense_pack_i8``:
+    same bytes; a wave's B-fragment loads are contiguous); ``packed=False`` keeps the row-major matrix and searches that."""
 
-    def __init__(self, corpus_int8, corpus_scales, device="cuda:0", doc_base: int = 0):
+    def __init__(self, corpus_int8, corpus_scales, device="cuda:0", doc_base: int = 0, packed: bool = True):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _capi.SparseRxUnavailable("no HIP device visible: DenseInt8Index needs a GPU (there is no CPU fallback)")
@@ -78,8 +79,19 @@ class DenseInt8Index:
         self.n_docs, self.dim = int(c.shape[0]), int(c.shape[1])
         self.dim_pad = _pad_dim(self.dim)
         with torch.cuda.device(self.device):
-            self.corpus = torch.zeros((self.n_docs, self.dim_pad), dtype=torch.int8, device=self.device)
-            self.corpus[:, : self.dim] = c.to(self.device)
+            rows = torch.zeros((self.n_docs, self.dim_pad), dtype=torch.int8, device=self.device)
+            rows[:, : self.dim] = c.to(self.device)
+            self.packed = bool(packed)
+            if self.packed:
+                L = _capi.lib()
+                nbytes = _capi.check(L.srx_dense_packed_bytes(self.n_docs, self.dim_pad), "srx_dense_packed_bytes")
+                self.corpus = torch.empty(nbytes, dtype=torch.int8, device=self.device)
+                _capi.check(L.srx_dense_pack_i8(self.device.index or 0, _ptr(rows), self.n_docs, self.dim_pad, _ptr(self.corpus),
+                                                _stream_ptr(torch, self.device)), "srx_dense_pack_i8")
+                torch.cuda.synchronize(self.device)
+                del rows
+            else:
+                self.corpus = rows
             s = corpus_scales if isinstance(corpus_scales, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(corpus_scales, dtype=np.float32))
             self.scales = s.to(device=self.device, dtype=torch.float32).contiguous()
         assert self.scales.numel() == self.n_docs
@@ -104,9 +116,10 @@ class DenseInt8Index:
             need = _capi.check(L.srx_dense_workspace_bytes(nq, self.n_docs, k), "srx_dense_workspace_bytes")
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            rc = L.srx_dense_search_i8(self.device.index or 0, _ptr(self.corpus), _ptr(self.scales), self.n_docs, self.dim_pad,
-                                       _ptr(q), _ptr(qs), nq, k, self.doc_base, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                       _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
+            fn = L.srx_dense_search_i8_packed if self.packed else L.srx_dense_search_i8
+            rc = fn(self.device.index or 0, _ptr(self.corpus), _ptr(self.scales), self.n_docs, self.dim_pad,
+                    _ptr(q), _ptr(qs), nq, k, self.doc_base, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                    _ptr(self._ws), self._ws.numel(), _stream_ptr(torch, self.device))
             _capi.check(rc, "srx_dense_search_i8")
         return out
 

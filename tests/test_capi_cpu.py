@@ -39,6 +39,11 @@ def test_limits_and_error_strings():
     assert L.srx_build_term_bounds(0, 0, None, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"srx_build_term_bounds" in L.srx_last_error()
     assert L.srx_build_term_bounds(0, 0, 1 << 19, 1 << 20, 10, 1 << 21, 65, 1 << 22, 1 << 23, None) == -1 and b"nk" in L.srx_last_error()
     assert L.srx_build_term_bounds(0, 7, 1 << 19, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"val_type" in L.srx_last_error()
+    assert L.srx_dense_packed_bytes(1000, 768) == 1024 * 768 and L.srx_dense_packed_bytes(33, 32) == 64 * 32
+    assert L.srx_dense_packed_bytes(10, 48) == -1 and b"srx_dense_packed_bytes" in L.srx_last_error()
+    assert L.srx_dense_pack_i8(0, None, 10, 64, 1 << 20, None) == -1 and b"srx_dense_pack_i8" in L.srx_last_error()
+    assert L.srx_dense_pack_i8(0, (1 << 20) + 8, 10, 64, 1 << 21, None) == -1 and b"aligned" in L.srx_last_error()
+    assert L.srx_dense_search_i8_packed(0, 1 << 20, 1 << 21, 10, 48, 1 << 22, 1 << 23, 1, 5, 0, 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 20, None) == -1
     assert L.srx_dense_search_u8(0, 1 << 20, None, 10, 64, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1
     assert L.srx_dense_search_u8(0, 1 << 20, 1 << 26, 10, 48, 1 << 21, 1, 5, 0, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 20, None) == -1
     assert b"multiple of 64" in L.srx_last_error()

@@ -71,6 +71,9 @@ def test_dense_int8_matches_oracle_bit_exact():
         assert np.array_equal(n, en), (n_docs, dim, nq, k)
         assert np.array_equal(s.view(np.uint32), es.view(np.uint32)), (n_docs, dim, nq, k)
         assert np.array_equal(d, ed), (n_docs, dim, nq, k)
+        # the row-major corpus (what the reference holds) through srx_dense_search_i8: the same rows as the fragment-ordered default
+        d2, s2, n2 = sparse_rx.DenseInt8Index(c, cs, doc_base=1000, packed=False).search(q, qs, kk)
+        assert np.array_equal(n2, n) and np.array_equal(d2, d) and np.array_equal(s2.view(np.uint32), s.view(np.uint32)), (n_docs, dim)
 
 
 @pytest.mark.gpu

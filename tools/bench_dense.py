@@ -18,7 +18,7 @@ c = torch.randint(-127, 128, (n_docs, dim), generator=g, device=dev, dtype=torch
 cs = torch.rand(n_docs, generator=g, device=dev) + 0.01
 q = torch.randint(-127, 128, (nq, dim), generator=g, device=dev, dtype=torch.int32).to(torch.int8)
 qs = (torch.rand(nq, generator=g, device=dev) + 0.01) / 127
-ix = sparse_rx.DenseInt8Index(c, cs)
+ix = sparse_rx.DenseInt8Index(c, cs, packed=not os.environ.get("SRX_DENSE_ROWMAJOR"))  # dev: the row-major corpus for comparison
 for _ in range(2):
     out = ix.search_device(q, qs, k)
 torch.cuda.synchronize()
