@@ -1,4 +1,4 @@
-"""N > 1 path under gloo on the CPU (world_size 2 and 3): shard ranges, corpus-wide statistics by all-reduce /
+"""N > 1 path under gloo on the CPU (world_size 2, 3 and -- the size of the node the scaling bench runs on -- 8): shard ranges, corpus-wide statistics by all-reduce /
 all-gather, the all-gather of per-shard top-k and the exact merge.  The per-shard scoring is done by the CPU oracle
 here (tests may use it; the product wiring ShardedSearcher.for_device_index uses the HIP engine and is covered by the
 GPU tests + bench.py --gpus N)."""
@@ -107,7 +107,7 @@ def _worker(rank, world, port, mode, ret):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "a2a"), (3, "a2a"), (2, "allgather"), (3, "allgather"), (2, "a2a+packed"),
-                                        (3, "a2a+packed"), (3, "allgather+packed")])
+                                        (3, "a2a+packed"), (3, "allgather+packed"), (8, "a2a+packed"), (8, "allgather")])
 def test_sharded_search_matches_single_shard(world, mode):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
@@ -280,7 +280,7 @@ def _service_worker(rank, world, port, golden_dir, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_retrieval_service_shards_under_torch_distributed(world, golden_dir):
     """RetrievalService.build_bm25_index / search_bm25 (retrieval.py:129-231) called by every rank of a gloo group: the
     corpus-wide vocabulary / idf / avgdl equal the reference's, the rank holds its doc range only, and the dicts every
