@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SRX_VERSION 301 /* 0.3.1: + srx_search_after (ranking of any depth), srx_build_term_bounds, packed dense corpus */
+#define SRX_VERSION 301 /* 0.3.1: + srx_search_after (ranking of any depth), srx_build_term_bounds, srx_build_sum_duplicates, packed dense corpus */
 
 typedef enum {
     SRX_OK = 0,
@@ -235,6 +235,11 @@ int srx_build_blocks(int32_t device, int32_t val_type, const int64_t *term_ptr, 
                      const int32_t *post_doc, const void *post_val, const int32_t *skip, const int64_t *runpad,
                      int64_t vocab, int64_t nnz, int32_t n_tiles, int32_t tile_log2, int32_t unit_tiles, int32_t *out_post,
                      int32_t *out_skip, int64_t *out_term_ptr, int64_t n_blocks, void *stream);
+
+/* Duplicate (doc, term) entries of a COO input (adjacent after the stable sort by term): out_sum[g] = val[first[g]] + ... +
+ * val[first[g + 1] - 1], added left to right -- what SciPy does when the reference assembles its CSR from triples
+ * (csr_matrix((data, (rows, cols))), rag_system/core/retrieval.py:171-175).  first i64[n_groups + 1] ascending. */
+int srx_build_sum_duplicates(int32_t device, const int64_t *first, int64_t n_groups, const float *val, float *out_sum, void *stream);
 
 /* Per-term score bounds (srx_index_desc.term_bound and the finer table the sharded build combines): out_bound[t * nk + j] =
  * the ks[j]-th largest value of term t's run post_val[term_ptr[t] .. term_ptr[t + 1]) of the term-major value array (before

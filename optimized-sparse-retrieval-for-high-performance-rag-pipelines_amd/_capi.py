@@ -80,6 +80,7 @@ SYMBOLS = {
     "srx_build_blocks": (ctypes.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I64, _VP]),
     "srx_build_compact": (ctypes.c_int, [_I32, _I32, _VP, _I64, _I32, _I32, _VP, _VP]),
     "srx_build_term_bounds": (ctypes.c_int, [_I32, _I32, _VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP]),
+    "srx_build_sum_duplicates": (ctypes.c_int, [_I32, _VP, _I64, _VP, _VP, _VP]),
     "srx_profile_read": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
 }
 

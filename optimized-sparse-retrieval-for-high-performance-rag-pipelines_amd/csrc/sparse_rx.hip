@@ -2059,6 +2059,33 @@ SRX_API int srx_build_term_bounds(int32_t device, int32_t val_type, const int64_
     return SRX_OK;
 }
 
+// Duplicate (doc, term) entries of a COO input, adjacent after the stable term sort: group g = entries
+// [first[g], first[g + 1]) is summed left to right in input order, like SciPy sums duplicates when the reference assembles
+// its CSR (csr_matrix((data, (rows, cols))), retrieval.py:171-175).  One thread per group (groups are almost all of length 1).
+namespace {
+__global__ __launch_bounds__(256) void srx_sum_groups_kernel(const int64_t *__restrict__ first, int64_t n_groups,
+                                                             const float *__restrict__ val, float *__restrict__ out) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * 256) {
+        const int64_t a = first[g], b = first[g + 1];
+        float s = val[a];
+        for (int64_t i = a + 1; i < b; ++i) s = s + val[i];
+        out[g] = s;
+    }
+}
+}  // namespace
+
+SRX_API int srx_build_sum_duplicates(int32_t device, const int64_t *first, int64_t n_groups, const float *val, float *out_sum,
+                                     void *stream_v) {
+    if (n_groups < 0 || (n_groups > 0 && (!first || !val || !out_sum))) return fail(SRX_ERR_INVALID, "srx_build_sum_duplicates: bad argument%s");
+    if (n_groups == 0) return SRX_OK;
+    HIP_TRY(hipSetDevice(device));
+    int64_t blocks = (n_groups + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(srx_sum_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v, first, n_groups, val, out_sum);
+    HIP_TRY(hipGetLastError());
+    return SRX_OK;
+}
+
 SRX_API int srx_build_tile_skip(int32_t device, const int64_t *term_ptr, const int32_t *post_doc, int64_t vocab,
                                 int32_t n_tiles, int32_t tile_log2, int32_t *out_skip, void *stream_v) {
     if (!term_ptr || !out_skip || vocab <= 0 || n_tiles <= 0 || tile_log2 < 0 || tile_log2 > 30)

@@ -326,19 +326,18 @@ class DeviceIndex:
                     if bool(dup.any().item()):
                         first = torch.ones(nnz, dtype=torch.bool, device=dev)
                         first[1:] = ~dup
-                        gid = torch.cumsum(first.to(torch.int64), 0) - 1
-                        ar = torch.arange(nnz, device=dev, dtype=torch.int64)
-                        pos = ar - torch.cummax(torch.where(first, ar, torch.zeros_like(ar)), 0).values  # rank inside its group
-                        merged = tf[first].clone()
-                        for j in range(1, int(pos.max().item()) + 1):  # one add per group and step: deterministic, input order
-                            m = pos == j
-                            merged[gid[m]] += tf[m]
+                        starts = torch.nonzero(first).squeeze(1)
+                        starts = torch.cat([starts, torch.tensor([nnz], dtype=torch.int64, device=dev)]).contiguous()
+                        merged = torch.empty(starts.numel() - 1, dtype=torch.float32, device=dev)
+                        _capi.check(L.srx_build_sum_duplicates(dev.index or 0, _ptr(starts), starts.numel() - 1, _ptr(tf), _ptr(merged),
+                                                               _stream_ptr(torch, dev)), "srx_build_sum_duplicates")  # left to right, input order
+                        torch.cuda.synchronize(dev)
                         tf = merged
-                        del ar, pos, merged
+                        del starts, merged
                         cols_sorted, post_doc = cols_sorted[first].contiguous(), post_doc[first].contiguous()
                         nnz = cols_sorted.numel()
                         df = torch.bincount(cols_sorted, minlength=V)
-                        del first, gid
+                        del first
                     del dup
             else:
                 post_doc = torch.zeros(0, dtype=torch.int32, device=dev)

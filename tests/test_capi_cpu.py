@@ -39,6 +39,8 @@ def test_limits_and_error_strings():
     assert L.srx_build_term_bounds(0, 0, None, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"srx_build_term_bounds" in L.srx_last_error()
     assert L.srx_build_term_bounds(0, 0, 1 << 19, 1 << 20, 10, 1 << 21, 65, 1 << 22, 1 << 23, None) == -1 and b"nk" in L.srx_last_error()
     assert L.srx_build_term_bounds(0, 7, 1 << 19, 1 << 20, 10, 1 << 21, 4, 1 << 22, 1 << 23, None) == -1 and b"val_type" in L.srx_last_error()
+    assert L.srx_build_sum_duplicates(0, None, 5, 1 << 20, 1 << 21, None) == -1 and b"srx_build_sum_duplicates" in L.srx_last_error()
+    assert L.srx_build_sum_duplicates(0, None, 0, None, None, None) == 0
     assert L.srx_dense_packed_bytes(1000, 768) == 1024 * 768 and L.srx_dense_packed_bytes(33, 32) == 64 * 32
     assert L.srx_dense_packed_bytes(10, 48) == -1 and b"srx_dense_packed_bytes" in L.srx_last_error()
     assert L.srx_dense_pack_i8(0, None, 10, 64, 1 << 20, None) == -1 and b"srx_dense_pack_i8" in L.srx_last_error()
