@@ -482,8 +482,12 @@ int dense_splits(int64_t n_docs, int nq, int k) {
 // be small: swept in profiles/r03_dense_filter_variants.log (k = 1 000: 2.51 ms at 8 k n / CAP, 2.19-2.22 ms at 2-4 k n / CAP).
 // 0 = corpus too small for the filtered path to pay.
 int64_t dense_sample(int64_t n_docs, int k) {
+    if (n_docs < 65536) return 0;
     int64_t S = (3 * (int64_t)k * n_docs + DENSE_CAP - 1) / DENSE_CAP;
-    if (S < 16384) S = 16384;
+    // at least ~k / 0.6 % docs (what the second round's tighter threshold makes of it costs little), 4 096 .. 16 384: for small k
+    // the sample pass itself is what counts (k = 10: 1.14 -> 1.11 ms at 4 096, sweep in profiles/r03_dense_filter_variants.log)
+    const int64_t floor_s = 164ll * k < 4096 ? 4096 : (164ll * k > 16384 ? 16384 : 164ll * k);
+    if (S < floor_s) S = floor_s;
 #ifdef SRX_DENSE_KNOBS  // dev build: scale the sample (tools/r3_run33.sh)
     if (const char *e = getenv("SRX_DENSE_SAMPLE_MULT")) S = (int64_t)((double)S * atof(e));
     if (S < 2048) S = 2048;
