@@ -246,7 +246,7 @@ int srx_build_sum_duplicates(int32_t device, const int64_t *first, int64_t n_gro
  * blocking; f32 or f16 by val_type), 0 where the term has fewer than ks[j] positive values.  ks i32[nk] on the device,
  * 1 <= ks[j] <= 1024, nk <= 64.  *neg_flag (device i32) is set to 1 when a value is negative: the bounds must then not be
  * used.  One streaming pass (the selection machinery of the search kernels); replaces no reference code: the reference has
- * no score bounds. */
+ * no score bounds.  Reads ks back to the host first (a stream synchronisation: this is a build step, not a search step). */
 int srx_build_term_bounds(int32_t device, int32_t val_type, const int64_t *term_ptr, const void *post_val, int64_t vocab,
                           const int32_t *ks, int32_t nk, float *out_bound, int32_t *neg_flag, void *stream);
 
